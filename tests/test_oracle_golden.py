@@ -1,0 +1,73 @@
+"""CPU: the oracle restatement reproduces the committed reference outputs (tests/golden, written by
+oracle/gen_golden.py from the unmodified reference model).  Tolerances: vs the fp64 reference output the
+fp32 oracle must sit at the fp32 noise floor (reference fp32-vs-fp64 itself is ~1e-5)."""
+import numpy as np
+import torch
+
+from oracle import tfgridnet_oracle as O
+from lookoncetohear_amd import synth
+
+TOL32 = 5e-5      # fp32 oracle vs fp64 reference truth
+TOL64 = 2e-6      # fp64 oracle vs fp64 reference truth stored as fp32 (rounding of the stored value)
+
+
+def _maxabs(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+def test_offline_cases(golden, oracle_cfg_sd):
+    cfg, sd = oracle_cfg_sd
+    for name, idx, n in (("off_b2_n8000", [0, 1], 8000), ("off_b1_n8100", [2], 8100)):
+        d = synth.batch(idx, n)
+        y32 = O.forward(cfg, sd, d["mixture"], d["embedding_gt"])
+        y64 = O.forward(cfg, sd, d["mixture"], d["embedding_gt"], dtype=torch.float64)
+        assert y32.shape == golden[name + "_y64"].shape
+        assert _maxabs(y32, golden[name + "_y64"]) < TOL32
+        assert _maxabs(y32, golden[name + "_y32"]) < TOL32
+        assert _maxabs(y64, golden[name + "_y64"]) < TOL64
+
+
+def test_nonzero_state_in_out(golden, oracle_cfg_sd):
+    cfg, sd = oracle_cfg_sd
+    d = synth.batch([3, 4], 128 * 12 + 64)
+    st = O.random_state(cfg, 2, 3)
+    y, st2 = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], st, pad=False)
+    assert _maxabs(y, golden["state_b2_y64"]) < TOL32
+    for k, v in O.flat_state(st2).items():
+        assert _maxabs(O.subsample(v, 256), golden["state_b2_s64." + k]) < TOL32, k
+
+
+def test_streaming_matches_reference_and_offline(golden, oracle_cfg_sd):
+    cfg, sd = oracle_cfg_sd
+    nchunk = 60
+    d = synth.batch([5], 128 * nchunk + 64)
+    st, outs = None, []
+    for i in range(nchunk):
+        y, st = O.predict(cfg, sd, d["mixture"][:, :, i * 128:i * 128 + 192], d["embedding_gt"][:, 0], st, pad=False)
+        outs.append(y)
+    ys = torch.cat(outs, -1)
+    assert _maxabs(ys, golden["stream_b1_y64"]) < TOL32
+    y_off, _ = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], None, pad=False)
+    assert _maxabs(ys, y_off) < TOL32          # streaming == offline invariant
+
+
+def test_full_clip_and_intermediates(golden, oracle_cfg_sd):
+    cfg, sd = oracle_cfg_sd
+    d = synth.batch([6], 80000)
+    taps = {}
+    y = O.forward(cfg, sd, d["mixture"], d["embedding_gt"], fast_lstm=True, taps=taps)
+    assert tuple(y.shape) == (1, 2, 80000)
+    assert _maxabs(y[:, :, ::8], golden["full_b1_y64"]) < TOL32
+    for k in ("Z0", "G", "blocks.0.Q", "blocks.1.K", "blocks.2.V", "blocks.0.out", "blocks.1.out", "blocks.2.out"):
+        assert _maxabs(O.subsample(taps[k]), golden["full_b1_t64." + k]) < TOL32, k
+
+
+def test_si_snr_definition():
+    g = torch.Generator().manual_seed(0)
+    t = torch.randn(3, 2, 4000, generator=g)
+    p = 0.7 * t + 0.1 * torch.randn(3, 2, 4000, generator=g) + 0.3
+    # scale / offset invariance and the closed form 10log10(|a t|^2/|a t - p|^2)
+    v = O.si_snr(p, t)
+    assert torch.allclose(v, O.si_snr(3.0 * p + 1.0, t), atol=1e-3)
+    assert v.shape == (3, 2) and (v > 10).all() and (v < 30).all()
+    assert O.si_snr_i(p, p, t).abs().max() < 1e-5
