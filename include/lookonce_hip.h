@@ -1,0 +1,132 @@
+/* lookonce_hip.h — C ABI of the MI355X-native LookOnceToHear separator forward path.
+ *
+ * Drop-in boundary: the reference selects its model by a dotted string
+ * (`utils.import_attr(model)(**model_params)`, reference src/ts_hear_embed_pl_module.py:25 with the string
+ * from configs/tsh.json:4).  `lookoncetohear_amd.net.Net` is that class; it owns parameters and streaming
+ * state as torch tensors and calls the stateless entry points below with raw device pointers on the current
+ * HIP stream.  Conventions (same as the only C-ABI precedent in the reference,
+ * src/datasets/motion_simulator.py:41-46): every function returns int, 0 = OK, and the caller asserts.
+ *   - all pointers are DEVICE pointers to fp32 unless stated; nothing is allocated or freed here;
+ *   - activations are channel-last  X[b][t][f][c]  (B,T,F=97,C=64);
+ *   - `*_in` / `*_out` state pairs must not alias (several workgroups read the old state while one writes
+ *     the new one);
+ *   - shape constants are those of configs/tsh.json (nfft 192, hop 128, F 97, C 64, H 64, heads 4, E 6,
+ *     Vd 16, window 50, 2 mics, 2 sources); `lh_check_config` returns LH_ERR_UNSUPPORTED for anything else.
+ *
+ * Each entry point cites the reference lines it replaces.
+ */
+#ifndef LOOKONCE_HIP_H
+#define LOOKONCE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lh_stream_t; /* hipStream_t */
+
+enum {
+    LH_OK = 0,
+    LH_ERR_ARG = 1,         /* null pointer / non-positive size */
+    LH_ERR_UNSUPPORTED = 2, /* shape constants differ from the compiled configuration */
+    LH_ERR_LAUNCH = 3       /* hipGetLastError() != hipSuccess after the launch */
+};
+
+/* ABI version of this header; bumped on any signature change. */
+int lh_abi_version(void);
+
+/* Validates model_params (reference net.py:21-49 / configs/tsh.json:5-19) against the compiled constants. */
+int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unused, int lstm_hidden,
+                    int n_heads, int attn_window, int n_srcs, int spk_emb_dim);
+
+/* A.1  STFT analysis + re/im channel split + causal 3x3 Conv2d(4->64).
+ * Replaces tfgridnet_causal.py:229-242 (asteroid Encoder conv1d, cat/transpose, conv_buf halo, self.conv).
+ *   x            [B][2][n_samples]                 n_samples = 128*T + 64
+ *   conv_buf_in  [B][4][2][97]   conv_buf_out same shape (last two frames of the halo-extended spectrum)
+ *   wfb_t        [192][194]      enc.filterbank._filters transposed (n-major)
+ *   wconv_pk     [36][64]        conv.0.weight as [(ch*3+kt)*3+kf][o];  bconv [64]
+ *   z            [B][T][97][64]  out
+ */
+int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* conv_buf_out, const float* wfb_t,
+                    const float* wconv_pk, const float* bconv, float* z, int B, int T, int n_samples,
+                    lh_stream_t stream);
+
+/* A.2  speaker gain  g = LayerNorm_6208(W e + b)  stored f-major:  gain[b][f][c] = g[b][c*97+f].
+ * Replaces tfgridnet_causal.py:247-248 (embed_to_feats_proj + reshape).
+ *   emb [B][256]; w [6208][256]; bias, ln_w, ln_b [6208]; gain [B][97][64] out
+ */
+int lh_embed_proj_ln(const float* emb, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                     float* gain, int B, lh_stream_t stream);
+
+/* A.3.1  intra-frame path: LayerNorm(C) -> BiLSTM over frequency (zero initial state) ; hidden states only.
+ * Replaces tfgridnet_causal.py:505-512 (intra_norm, intra_rnn).
+ *   x      [B*T][97][64]
+ *   ln_w/b [64]
+ *   w_pk   [2 dirs][4 waves][4 gates][32 ksteps][64 lanes]  MFMA B-operand image of [W_ih | W_hh]^T (see
+ *          lookoncetohear_amd/weights.py: pack_lstm);  b_sum [2][256] = bias_ih + bias_hh
+ *   h_out  [B*T*97][128]   (forward hidden in cols 0..63, reverse in 64..127)
+ */
+int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* ln_b, const float* w_pk, const float* b_sum,
+                     float* h_out, int n_frames /* B*T */, lh_stream_t stream);
+
+/* A.3.2  inter-frame path: LayerNorm(C) -> causal LSTM over time with carried state ; hidden states only.
+ * Replaces tfgridnet_causal.py:521-532 (inter_norm, transpose/reshape to [B*F,T,C], inter_rnn, h0/c0 in/out).
+ *   x [B][T][97][64]; h0,c0,hN,cN [B*97][64] (sequence index b*97+f); w_pk [1][4][4][32][64]; b_sum [256]
+ *   h_out [B*T*97][64] in the same (b,t,f) row order as x
+ */
+int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const float* w_pk, const float* b_sum,
+                     const float* h0, const float* c0, float* hN, float* cN, float* h_out, int B, int T,
+                     lh_stream_t stream);
+
+/* Row-wise Linear(K->64) + bias + residual:  out[r][:] = res[r][:] + W h[r][:] + b.
+ * Replaces intra_linear + residual (tfgridnet_causal.py:513-516, K=128) and inter_linear + view/transpose +
+ * residual (:534-538, K=64).   h [rows][K]; w_pk [4 ntiles][K/4 ksteps][64 lanes]; bias [64]; res,out [rows][64]
+ */
+int lh_linear_res(const float* h, const float* w_pk, const float* bias, const float* res, float* out, int rows,
+                  int K, lh_stream_t stream);
+
+/* A.3.3  Q/K/V: pointwise Linear + PReLU, head split, joint LayerNorm over (f,e) per head.
+ * Replaces attn_conv_Q/K/V (tfgridnet_causal.py:354-387, used :547-551) and the K/V history concat (:553-562):
+ * K and V rows are written at row (hist + t) of the history-extended buffers.
+ *   y      [B][T][97][64]
+ *   w_pk   [7 ntiles][16 ksteps][64 lanes]  rows 0..23 Q(h*6+e), 24..47 K, 48..111 V(h*16+v); bias [112]
+ *   slopes [3] PReLU slopes (Q,K,V);  lnq_w/b, lnk_w/b [582];  lnv_w/b [1552]
+ *   q      [B*4][T][584]            (row stride 584 = 582 padded to 16 B; pad columns are written as 0)
+ *   kx     [B*4][T+49][584]         rows 0..48 = history (filled by the caller from K_buf), row 49+t = K[t]
+ *   vx     [B*4][T+49][1552]
+ */
+int lh_qkv_proj_ln(const float* y, const float* w_pk, const float* bias, const float* slopes, const float* lnq_w,
+                   const float* lnq_b, const float* lnk_w, const float* lnk_b, const float* lnv_w,
+                   const float* lnv_b, float* q, float* kx, float* vx, int B, int T, lh_stream_t stream);
+
+/* A.3.5  local windowed attention over exactly 50 slots (frames t-49..t incl. history rows, no mask) with
+ * the head merge fused into the store.  Replaces tfgridnet_causal.py:564-581 without materialising the
+ * 50x unfolded K/V (`_causal_unfold_chunk`, :429-454).
+ *   q [B*4][T][584]; kx [B*4][T+49][584]; vx [B*4][T+49][1552]
+ *   merged [B][T][97][64]   merged[b][t][f][h*16+v] = O[b*4+h][t][f*16+v]
+ */
+int lh_local_attn(const float* q, const float* kx, const float* vx, float* merged, int B, int T,
+                  lh_stream_t stream);
+
+/* A.3.6  attn_concat_proj: Linear(64->64)+PReLU, joint LayerNorm over (f,c), residual; optional speaker gain.
+ * Replaces tfgridnet_causal.py:583-588 and, when gain != NULL, the `batch = batch * embed` applied to the
+ * input of block 1 (:250-251):  out = (y2 + LN(PReLU(W m + b))) * gain[b][f][c].
+ *   merged, y2, out [B][T][97][64]; w_pk [4][16][64]; bias [64]; slope [1]; ln_w/b [6208]; gain [B][97][64]|NULL
+ */
+int lh_proj_ln_res(const float* merged, const float* w_pk, const float* bias, const float* slope,
+                   const float* ln_w, const float* ln_b, const float* y2, const float* gain, float* out, int B,
+                   int T, lh_stream_t stream);
+
+/* A.4  causal ConvTranspose2d(64->4,3x3) + spectrum re-pack + iSTFT synthesis/overlap-add.
+ * Replaces tfgridnet_causal.py:256-273 and the look-ahead trim of net.py:61.
+ *   y [B][T][97][64]; deconv_buf_in/out [B][64][2][97]; istft_buf_in/out [B][2][194][1]
+ *   wdec_pk [4][3][3][64] deconv.weight as [o][kt][kf][c]; bdec [4]; wfb_dec [194][192]
+ *   wave_out [B][2][128*T]
+ */
+int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out, const float* istft_buf_in,
+                    float* istft_buf_out, const float* wdec_pk, const float* bdec, const float* wfb_dec,
+                    float* wave_out, int B, int T, lh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOOKONCE_HIP_H */

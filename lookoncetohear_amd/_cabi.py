@@ -1,0 +1,69 @@
+"""ctypes binding of the C-ABI library declared in include/lookonce_hip.h.
+
+The product path loads ONLY the hipcc-built gfx950 library `lookoncetohear_amd/_lookonce_hip.so` and fails
+loudly when it is missing: there is no CPU fallback (the CPU oracle under `oracle/` is test infrastructure).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
+ABI_VERSION = 1
+
+_P, _I = c_void_p, c_int
+# name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
+SIGNATURES = {
+    "lh_abi_version": [],
+    "lh_check_config": [_I] * 10,
+    "lh_stft_conv_in": [_P] * 7 + [_I] * 3 + [_P],
+    "lh_embed_proj_ln": [_P] * 6 + [_I, _P],
+    "lh_ln_lstm_intra": [_P] * 6 + [_I, _P],
+    "lh_ln_lstm_inter": [_P] * 10 + [_I, _I, _P],
+    "lh_linear_res": [_P] * 5 + [_I, _I, _P],
+    "lh_qkv_proj_ln": [_P] * 13 + [_I, _I, _P],
+    "lh_local_attn": [_P] * 4 + [_I, _I, _P],
+    "lh_proj_ln_res": [_P] * 9 + [_I, _I, _P],
+    "lh_deconv_istft": [_P] * 9 + [_I, _I, _P],
+}
+ERRORS = {1: "LH_ERR_ARG", 2: "LH_ERR_UNSUPPORTED", 3: "LH_ERR_LAUNCH"}
+
+
+class Lib:
+    """A loaded C-ABI library with typed entry points; every call asserts the 0 = OK convention."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: the HIP extension is not built. Run `python -m lookoncetohear_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(self._dll, name)          # AttributeError here = missing export
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        v = self._dll.lh_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI version {v}, expected {ABI_VERSION}")
+
+    def call(self, name: str, *args) -> None:
+        rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            raise RuntimeError(f"{name} failed: {ERRORS.get(rc, rc)}")
+
+    def raw(self, name: str):
+        return getattr(self._dll, name)
+
+
+_hip_lib = None
+
+
+def load() -> Lib:
+    """The gfx950 library (cached). Raises if it has not been built."""
+    global _hip_lib
+    if _hip_lib is None:
+        _hip_lib = Lib(HIP_LIB_PATH)
+    return _hip_lib

@@ -1,0 +1,56 @@
+"""Builds the gfx950 C-ABI library in-tree with hipcc (cross-compiles without a GPU).
+
+    python -m lookoncetohear_amd.build [--force]
+
+Output: lookoncetohear_amd/_lookonce_hip.so (git-ignored, but it travels to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip"]
+LIB = os.path.join(PKG, "_lookonce_hip.so")
+ARCH = "gfx950"
+
+
+def _newer(dst, srcs):
+    if not os.path.exists(dst):
+        return False
+    t = os.path.getmtime(dst)
+    return all(os.path.getmtime(s) <= t for s in srcs)
+
+
+def build_hip(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "lh_common.h"),
+                                                       os.path.join(os.path.dirname(PKG), "include", "lookonce_hip.h")]
+    if not force and _newer(LIB, deps):
+        return LIB
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv))

@@ -1,0 +1,61 @@
+// Shared compile-time shape constants and device helpers for the gfx950 kernels.
+// Shapes are those of the reference configs/tsh.json: the kernels are specialised on them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/lookonce_hip.h"
+
+namespace lh {
+
+constexpr int NFFT = 192;        // stft_chunk_size + stft_pad_size (net.py:32)
+constexpr int HOP = 128;         // stft_chunk_size
+constexpr int NF = 97;           // n_fft/2 + 1 frequency bins
+constexpr int NK = 2 * NF;       // filterbank rows (re | im)
+constexpr int NMIC = 2;
+constexpr int NSRC = 2;
+constexpr int C = 64;            // emb_dim
+constexpr int H = 64;            // lstm_hidden_units
+constexpr int NH = 4;            // attention heads
+constexpr int E = 6;             // ceil(512/97)
+constexpr int VD = 16;           // C / NH
+constexpr int DQK = NF * E;      // 582
+constexpr int LDQK = 584;        // padded row stride of q / kx (16-byte aligned rows)
+constexpr int DV = NF * VD;      // 1552
+constexpr int WIN = 50;          // local_atten_len
+constexpr int HIST = WIN - 1;    // 49 history rows
+constexpr int NQKV = NH * E * 2 + NH * VD;   // 112 projection outputs (Q 24 | K 24 | V 64)
+constexpr int SPK = 256;         // spk_emb_dim
+constexpr float LN_EPS = 1e-5f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh via exp(2x): saturates correctly (exp -> inf gives 1, exp -> 0 gives -1); abs error ~1e-7
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
+
+// sum over the 64 lanes of a wave (every lane gets the total)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// sum over aligned groups of 16 lanes
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum `v` over all threads of a 256-thread workgroup; `red` is a >= 4-float LDS scratch.
+// Contains two barriers; every thread must call it.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();                       // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? LH_OK : LH_ERR_LAUNCH; }
+
+}  // namespace lh

@@ -1,0 +1,226 @@
+// Persistent LayerNorm + LSTM recurrence kernel (the dominant kernel: 77 % of the path's FLOPs,
+// SURVEY.md §8a rows a8/a9/a11).
+//
+// One workgroup (4 waves, one per SIMD) owns NS = 16*MT sequences of one direction for ALL time steps:
+//   * [W_ih | W_hh]^T (128 x 256 fp32) lives in VGPRs for the whole kernel as MFMA B-operand fragments:
+//     wave w owns hidden units 16w..16w+15 of all four gates (i,f,g,o), i.e. 4 gate tiles x 32 k-steps =
+//     128 registers per lane, so the cell update is lane-local (all four gates of a (sequence, unit) pair
+//     land in the same lane of the v_mfma_f32_16x16x4_f32 accumulators);
+//   * per step the A operand [NS x 128] = [LayerNorm(x_t) | h_{t-1}] is staged in LDS (double buffered,
+//     one barrier per step); k is permuted so each lane reads 32 contiguous floats (ds_read_b128);
+//   * exact fp32 MFMA (bitwise an fmaf chain) keeps the 625-step recurrences inside the 1e-3 budget;
+//   * x_{t+1} is fetched and normalised while step t computes; h_t is written back coalesced from LDS.
+#include "lh_common.h"
+
+namespace lh {
+
+constexpr int LS_PAD = 36;   // LDS row of a 32-float k-chunk (+4 floats: conflict-free ds_read_b128, 16 B aligned)
+
+template <int MT>
+__global__ void __launch_bounds__(256) k_ln_lstm(const float* __restrict__ x, const float* __restrict__ lnw,
+                                                 const float* __restrict__ lnb, const float* __restrict__ w_pk,
+                                                 const float* __restrict__ b_sum, const float* __restrict__ h0,
+                                                 const float* __restrict__ c0, float* __restrict__ hN,
+                                                 float* __restrict__ cN, float* __restrict__ h_out, int nseq,
+                                                 int nstep, int sdiv, int so, int si, int ps, int ldh) {
+    constexpr int NS = 16 * MT;
+    __shared__ __attribute__((aligned(16))) float abuf[2 * 4 * NS * LS_PAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y;
+    const int s0 = blockIdx.x * NS;
+    const int g4 = lane >> 4, l15 = lane & 15;
+
+    auto A = [&](int buf, int chunk, int row, int j) -> float* {
+        return &abuf[((buf * 4 + chunk) * NS + row) * LS_PAD + j];
+    };
+    auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
+    auto step_pos = [&](int it) -> int { return dir ? (nstep - 1 - it) : it; };
+
+    // ---- resident weights: B-operand fragments of this wave's 64 gate columns
+    float wreg[4][32];
+    {
+        const float* wp = w_pk + ((long)(dir * 4 + wave) * 4) * 32 * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) wreg[g][ks] = wp[(g * 32 + ks) * 64];
+    }
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + wave * 16 + l15];
+
+    // ---- per-thread role in the row-wise phases: 16 lanes per 64-float row, float4 each
+    const int q = tid & 15;                       // float4 index within the row
+    const float4 gw = *reinterpret_cast<const float4*>(&lnw[q * 4]);
+    const float4 gb = *reinterpret_cast<const float4*>(&lnb[q * 4]);
+
+    auto load_x = [&](int it, float4 (&xr)[MT]) {
+        const int p = step_pos(it);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            const int s = min(s0 + rl, nseq - 1);
+            xr[i] = *reinterpret_cast<const float4*>(&x[row_of(s, p) * C + q * 4]);
+        }
+    };
+    auto norm_store_x = [&](int buf, float4 (&xr)[MT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            float4 v = xr[i];
+            const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+            v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+            const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+            const float rstd = rsqrtf(var + LN_EPS);
+            float4 y;
+            y.x = v.x * rstd * gw.x + gb.x; y.y = v.y * rstd * gw.y + gb.y;
+            y.z = v.z * rstd * gw.z + gb.z; y.w = v.w * rstd * gw.w + gb.w;
+            *reinterpret_cast<float4*>(A(buf, q >> 3, rl, (q & 7) * 4)) = y;
+        }
+    };
+    auto flush_h = [&](int buf, int it) {          // h of step `it` (in LDS buffer `buf`) -> global, coalesced
+        const int p = step_pos(it);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            const int s = s0 + rl;
+            if (s < nseq) {
+                const float4 hv = *reinterpret_cast<const float4*>(A(buf, 2 + (q >> 3), rl, (q & 7) * 4));
+                *reinterpret_cast<float4*>(&h_out[row_of(s, p) * ldh + dir * H + q * 4]) = hv;
+            }
+        }
+    };
+
+    // ---- prologue: x of step 0, initial state
+    float creg[MT][4];
+    {
+        float4 xr[MT];
+        load_x(0, xr);
+        norm_store_x(0, xr);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            const int s = min(s0 + rl, nseq - 1);
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
+            *reinterpret_cast<float4*>(A(0, 2 + (q >> 3), rl, (q & 7) * 4)) = hv;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = min(s0 + m * 16 + g4 * 4 + r, nseq - 1);
+                creg[m][r] = c0 ? c0[(long)s * H + wave * 16 + l15] : 0.0f;
+            }
+    }
+    __syncthreads();
+
+    for (int it = 0; it < nstep; ++it) {
+        const int cur = it & 1, nxt = cur ^ 1;
+        float4 xr[MT];
+        const bool more = (it + 1 < nstep);
+        if (more) load_x(it + 1, xr);             // in flight during the MFMA phase
+        if (it > 0) flush_h(cur, it - 1);
+
+        // gates = [x_t | h_{t-1}] * [W_ih | W_hh]^T + b   (K = 128 as 32 k-steps of 4)
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[m][g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* arow = A(cur, g4, m * 16 + l15, 0);
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wreg[g][qq * 4 + j], acc[m][g], 0, 0, 0);
+            }
+        }
+
+        // cell update, lane-local: accumulator reg r <-> sequence row m*16 + g4*4 + r, unit wave*16 + l15
+        const int unit = wave * 16 + l15;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = sigmoid_f(acc[m][0][r]);
+                const float fg = sigmoid_f(acc[m][1][r]);
+                const float gg = tanh_f(acc[m][2][r]);
+                const float og = sigmoid_f(acc[m][3][r]);
+                const float cc = fg * creg[m][r] + ig * gg;
+                creg[m][r] = cc;
+                *A(nxt, 2 + (unit >> 5), m * 16 + g4 * 4 + r, unit & 31) = og * tanh_f(cc);
+            }
+        if (more) norm_store_x(nxt, xr);
+        __syncthreads();
+    }
+
+    // ---- epilogue: last hidden state to the sequence output, final (h, c) to the carried state
+    const int last = nstep & 1;
+    flush_h(last, nstep - 1);
+    if (hN) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            const int s = s0 + rl;
+            if (s < nseq)
+                *reinterpret_cast<float4*>(&hN[(long)s * H + q * 4]) =
+                    *reinterpret_cast<const float4*>(A(last, 2 + (q >> 3), rl, (q & 7) * 4));
+        }
+    }
+    if (cN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = s0 + m * 16 + g4 * 4 + r;
+                if (s < nseq) cN[(long)s * H + wave * 16 + l15] = creg[m][r];
+            }
+    }
+}
+
+template <int MT>
+static int launch_lstm(const float* x, const float* lnw, const float* lnb, const float* w_pk, const float* b_sum,
+                       const float* h0, const float* c0, float* hN, float* cN, float* h_out, int nseq, int nstep,
+                       int ndir, int sdiv, int so, int si, int ps, int ldh, hipStream_t st) {
+    constexpr int NS = 16 * MT;
+    hipLaunchKernelGGL((k_ln_lstm<MT>), dim3((nseq + NS - 1) / NS, ndir), dim3(256), 0, st, x, lnw, lnb, w_pk, b_sum,
+                       h0, c0, hN, cN, h_out, nseq, nstep, sdiv, so, si, ps, ldh);
+    return check_launch();
+}
+
+}  // namespace lh
+
+extern "C" int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* ln_b, const float* w_pk,
+                                const float* b_sum, float* h_out, int n_frames, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !ln_w || !ln_b || !w_pk || !b_sum || !h_out || n_frames <= 0) return LH_ERR_ARG;
+    // sequence s = frame (b,t); step p = frequency bin; row(s,p) = s*97 + p
+    if (n_frames >= 8192)
+        return launch_lstm<2>(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1,
+                              NF, 0, 1, 2 * H, (hipStream_t)stream);
+    return launch_lstm<1>(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1, NF,
+                          0, 1, 2 * H, (hipStream_t)stream);
+}
+
+extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const float* w_pk,
+                                const float* b_sum, const float* h0, const float* c0, float* hN, float* cN,
+                                float* h_out, int B, int T, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !ln_w || !ln_b || !w_pk || !b_sum || !h0 || !c0 || !hN || !cN || !h_out || B <= 0 || T <= 0)
+        return LH_ERR_ARG;
+    if (h0 == hN || c0 == cN) return LH_ERR_ARG;
+    // sequence s = b*97 + f; step p = frame t; row(s,p) = (b*T + p)*97 + f
+    const int nseq = B * NF;
+    if (nseq >= 32768)
+        return launch_lstm<2>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
+                              (hipStream_t)stream);
+    return launch_lstm<1>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
+                          (hipStream_t)stream);
+}

@@ -1,0 +1,302 @@
+"""`Net` — MI355X-native drop-in for the reference separator `src.models.tfgridnet_realtime.net.Net`.
+
+Installation = changing one string in the reference config (configs/tsh.json:4):
+
+    "model": "lookoncetohear_amd.net.Net"
+
+because the reference builds its model with `utils.import_attr(model)(**model_params)`
+(reference src/ts_hear_embed_pl_module.py:25).  This class therefore mirrors, exactly:
+
+  * the constructor keywords and defaults of reference net.py:21-24 (configs/tsh.json:5-19 pass unchanged);
+  * `forward(x, embeds, input_state=None, pad=True)`, `predict(x, embed, input_state, pad=True)`,
+    `init_buffers(batch_size, device)` (reference net.py:51-76) with the same state-dict-of-tensors layout
+    (reference tfgridnet_causal.py:173-186, 408-427), mutated and returned like the reference does;
+  * the parameter / buffer names and shapes of the reference module tree (`tfgridnet.blocks.0.intra_rnn.
+    weight_ih_l0`, ... SURVEY.md §8b), so a reference Lightning checkpoint loads with strict=True, and the same
+    construction order, so `torch.manual_seed(s); Net(**params)` draws the same initial weights.
+
+The torch modules below are parameter containers only: they are never called.  All arithmetic runs in the
+hand-written gfx950 kernels behind the C ABI of include/lookonce_hip.h; there is no CPU fallback (the product
+path raises if the HIP library is missing or the tensors are not on the GPU).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _cabi
+from .weights import pack_all
+
+
+def mod_pad(x: torch.Tensor, chunk_size: int, pad: Tuple[int, int]):
+    """Right-pad to a multiple of `chunk_size`, then apply `pad` (reference net.py:8-18)."""
+    mod = 0
+    if x.shape[-1] % chunk_size != 0:
+        mod = chunk_size - (x.shape[-1] % chunk_size)
+    x = F.pad(x, (0, mod))
+    x = F.pad(x, pad)
+    return x, mod
+
+
+def stft_filterbank(n_fft: int, hop: int) -> torch.Tensor:
+    """Analysis/synthesis filterbank buffer `[n_fft + 2, 1, n_fft]` (asteroid-filterbanks STFTFB as called at
+    reference tfgridnet_causal.py:131-135): sqrt-periodic-Hann windowed real-DFT rows, 97 cosine rows then 97
+    negative-sine rows, DC/Nyquist cosine rows scaled by 1/sqrt(2), overall 1/(0.5*sqrt(n_fft^2/hop))."""
+    nbin = n_fft // 2 + 1
+    n = np.arange(n_fft, dtype=np.float64)
+    window = np.sqrt(0.5 * (1.0 - np.cos(2.0 * np.pi * n / n_fft)))
+    ang = 2.0 * np.pi * np.outer(np.arange(nbin), n) / n_fft
+    rows = np.concatenate([np.cos(ang), -np.sin(ang)], axis=0)
+    rows[0] *= 1.0 / np.sqrt(2.0)
+    rows[n_fft // 2] *= 1.0 / np.sqrt(2.0)
+    rows *= window[None, :] / (0.5 * np.sqrt(n_fft * n_fft / hop))
+    return torch.from_numpy(rows).float().unsqueeze(1)
+
+
+class _FilterBank(nn.Module):
+    def __init__(self, n_fft, hop):
+        super().__init__()
+        self.register_buffer("_filters", stft_filterbank(n_fft, hop))
+
+
+class _Coder(nn.Module):          # name holder for `enc.filterbank._filters` / `dec.filterbank._filters`
+    def __init__(self, n_fft, hop):
+        super().__init__()
+        self.filterbank = _FilterBank(n_fft, hop)
+
+
+class _Norm(nn.Module):           # name holder for `*.norm.{weight,bias}`
+    def __init__(self, n, eps):
+        super().__init__()
+        self.norm = nn.LayerNorm(n, eps=eps)
+
+
+def _proj(n_in, n_out, n_norm, eps):
+    # Linear, PReLU (single slope, espnet2 get_layer("prelu")()), [reshape], joint LayerNorm -> indices 0,1,3
+    return nn.Sequential(nn.Linear(n_in, n_out), nn.PReLU(), nn.Identity(), _Norm(n_norm, eps))
+
+
+class _GridNetBlockParams(nn.Module):
+    """Parameters of one causal GridNet block, created in the reference order (tfgridnet_causal.py:334-396)."""
+
+    def __init__(self, emb_dim, n_freqs, hidden, n_head, eps):
+        super().__init__()
+        E = math.ceil(512 * 1.0 / n_freqs)
+        self.intra_norm = _Norm(emb_dim, eps)
+        self.intra_rnn = nn.LSTM(emb_dim, hidden, 1, batch_first=True, bidirectional=True)
+        self.intra_linear = nn.Linear(hidden * 2, emb_dim)
+        self.inter_norm = _Norm(emb_dim, eps)
+        self.inter_rnn = nn.LSTM(emb_dim, hidden, 1, batch_first=True, bidirectional=False)
+        self.inter_linear = nn.Linear(hidden, emb_dim)
+        self.attn_conv_Q = _proj(emb_dim, E * n_head, n_freqs * E, eps)
+        self.attn_conv_K = _proj(emb_dim, E * n_head, n_freqs * E, eps)
+        self.attn_conv_V = _proj(emb_dim, (emb_dim // n_head) * n_head, n_freqs * (emb_dim // n_head), eps)
+        self.attn_concat_proj = _proj(emb_dim, emb_dim, n_freqs * emb_dim, eps)
+
+
+class _TFGridNetParams(nn.Module):
+    """Parameter tree of the reference causal TFGridNet (tfgridnet_causal.py:113-171), same names/order."""
+
+    def __init__(self, n_fft, stride, n_imics, n_srcs, emb_dim, n_layers, hidden, n_head, spk_emb_dim, eps=1.0e-5):
+        super().__init__()
+        n_freqs = n_fft // 2 + 1
+        self.enc = _Coder(n_fft, stride)
+        self.dec = _Coder(n_fft, stride)
+        self.conv = nn.Sequential(nn.Conv2d(2 * n_imics, emb_dim, (3, 3), padding=(0, 1)))
+        self.blocks = nn.ModuleList(
+            [_GridNetBlockParams(emb_dim, n_freqs, hidden, n_head, eps) for _ in range(n_layers)])
+        self.embed_to_feats_proj = nn.Sequential(nn.Linear(spk_emb_dim, emb_dim * n_freqs),
+                                                 nn.LayerNorm(emb_dim * n_freqs))
+        self.deconv = nn.ConvTranspose2d(emb_dim, n_srcs * 2, (3, 3), padding=(2, 1))
+
+
+class Net(nn.Module):
+    def __init__(self, stft_chunk_size=160, stft_pad_size=120, embed_dim=256,
+                 num_ch=2, D=64, B=6, I=1, J=1, L=0, H=128,
+                 use_attn=False, lookahead=True, local_atten_len=100,
+                 chunk_causal=False, num_src=2):
+        super().__init__()
+        self.stft_chunk_size = stft_chunk_size
+        self.stft_pad_size = stft_pad_size
+        self.num_ch = num_ch
+        self.lookahead = lookahead
+        self.nfft = stft_chunk_size + stft_pad_size
+        # I, J (emb_ks / emb_hs) are accepted and unused, like the reference causal block (:399-400)
+        self.n_blocks, self.emb_dim, self.hidden, self.n_head = B, D, H, L
+        self.n_freqs = self.nfft // 2 + 1
+        self.local_atten_len = local_atten_len
+        self.n_srcs = num_src
+        self.spk_emb_dim = embed_dim
+        if not (use_attn and chunk_causal):
+            raise NotImplementedError("only the chunk-causal attention mode of configs/tsh.json is implemented")
+        shape = (self.nfft, stft_chunk_size, num_ch, D, H, L, local_atten_len, num_src, embed_dim)
+        if shape != (192, 128, 2, 64, 64, 4, 50, 2, 256):
+            raise NotImplementedError(
+                f"the gfx950 kernels are specialised on the configs/tsh.json shapes; got (nfft, hop, mics, D, H, L, "
+                f"window, srcs, embed_dim) = {shape}")
+        self.E = math.ceil(512 * 1.0 / self.n_freqs)
+        self.V_dim = D // L
+        self.tfgridnet = _TFGridNetParams(self.nfft, stft_chunk_size, num_ch, num_src, D, B, H, L, embed_dim)
+        self._pack_key = None
+        self._packed = None
+        self._ws: Dict[tuple, dict] = {}
+        self._lib_override = None          # TEST HOOK ONLY (tests/hipemu): never set on the product path
+        self._debug_taps: Optional[dict] = None
+
+    # ------------------------------------------------------------------------------------------------
+    # reference API
+    # ------------------------------------------------------------------------------------------------
+    def init_buffers(self, batch_size, device):
+        """Zero streaming state, reference shapes (tfgridnet_causal.py:173-186, 408-427)."""
+        z = lambda *s: torch.zeros(*s, device=device)
+        F_, C_, L_ = self.n_freqs, self.emb_dim, self.local_atten_len
+        bufs = {}
+        for i in range(self.n_blocks):
+            bufs[f"buf{i}"] = dict(K_buf=z(batch_size * self.n_head, L_ - 1, self.E * F_),
+                                   V_buf=z(batch_size * self.n_head, L_ - 1, self.V_dim * F_),
+                                   c0=z(1, batch_size * F_, self.hidden),
+                                   h0=z(1, batch_size * F_, self.hidden))
+        return dict(conv_buf=z(batch_size, self.num_ch * 2, 2, F_), deconv_buf=z(batch_size, C_, 2, F_),
+                    istft_buf=z(batch_size, self.n_srcs, F_ * 2, 1), gridnet_bufs=bufs)
+
+    def predict(self, x, embed, input_state, pad=True):
+        mod = 0
+        if pad:
+            pad_size = (0, self.stft_pad_size) if self.lookahead else (0, 0)
+            x, mod = mod_pad(x, chunk_size=self.stft_chunk_size, pad=pad_size)
+        x, next_state = self._separate(x, embed, input_state)
+        # the kernels already leave out the stft_pad_size look-ahead tail the reference trims at net.py:61
+        if mod != 0:
+            x = x[:, :, :-mod]
+        return x, next_state
+
+    def forward(self, x, embeds, input_state=None, pad=True):
+        embeds = embeds[:, 0]  # [B, E]
+        if input_state is None:
+            input_state = self.init_buffers(x.shape[0], x.device)
+        x, next_state = self.predict(x, embeds, input_state, pad)
+        return x
+
+    # ------------------------------------------------------------------------------------------------
+    # host-side plumbing
+    # ------------------------------------------------------------------------------------------------
+    def _lib(self, t: torch.Tensor) -> _cabi.Lib:
+        if self._lib_override is not None:
+            return self._lib_override
+        if not t.is_cuda:
+            raise RuntimeError("lookoncetohear_amd.Net runs on an MI355X (ROCm device tensors); there is no CPU "
+                               "path. Move the module and its inputs to cuda.")
+        return _cabi.load()
+
+    def _weights(self, device) -> dict:
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self._pack_key:
+            sd = {k: v for k, v in self.state_dict(keep_vars=True).items()}
+            for k, v in sd.items():
+                if v.device != device:
+                    raise RuntimeError(f"parameter {k} lives on {v.device}, input on {device}")
+            with torch.no_grad():
+                self._packed = pack_all(sd, self.n_blocks)
+            self._pack_key = key
+        return self._packed
+
+    def _workspace(self, B, T, device) -> dict:
+        key = (B, T, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 4:
+                self._ws.clear()
+            F_, C_, nh = self.n_freqs, self.emb_dim, self.n_head
+            e = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)
+            hist = self.local_atten_len - 1
+            ws = dict(xa=e(B, T, F_, C_), xb=e(B, T, F_, C_), xc=e(B, T, F_, C_), hbuf=e(B * T * F_, 2 * self.hidden),
+                      q=e(B * nh, T, 584), kx=torch.zeros(B * nh, T + hist, 584, device=device),
+                      vx=e(B * nh, T + hist, self.V_dim * F_), gain=e(B, F_, C_))
+            self._ws[key] = ws
+        return ws
+
+    def _separate(self, x: torch.Tensor, embed: torch.Tensor, state: Optional[dict]):
+        """TFGridNet.forward (reference tfgridnet_causal.py:188-283) on the HIP kernels."""
+        lib = self._lib(x)
+        dev = x.device
+        hop, nfft = self.stft_chunk_size, self.nfft
+        assert x.dim() == 3 and x.shape[1] == self.num_ch, "input must be [B, num_ch, N]"
+        Bn, _, n = x.shape
+        if state is None:
+            state = self.init_buffers(Bn, dev)
+        T = (n - nfft) // hop + 1
+        if T < 1:
+            raise ValueError(f"need at least {nfft} samples, got {n}")
+        ns = (T - 1) * hop + nfft
+        x = x[..., :ns].contiguous().float()
+        embed = embed.contiguous().float()
+        F_, C_, nh, H_ = self.n_freqs, self.emb_dim, self.n_head, self.hidden
+        hist = self.local_atten_len - 1
+        with torch.no_grad():
+            pk = self._weights(dev)
+            ws = self._workspace(Bn, T, dev)
+            st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
+            P = lambda t: t.data_ptr()
+            new = lambda t: torch.empty_like(t, dtype=torch.float32)
+            c32 = lambda t: t.contiguous().float()
+            taps = self._debug_taps
+            xa, xb, xc, hbuf = ws["xa"], ws["xb"], ws["xc"], ws["hbuf"]
+
+            conv_in = c32(state["conv_buf"]); conv_out = new(conv_in)
+            lib.call("lh_stft_conv_in", P(x), P(conv_in), P(conv_out), P(pk["wfb_t"]), P(pk["conv_w"]),
+                     P(pk["conv_b"]), P(xa), Bn, T, ns, st)
+            lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]),
+                     P(pk["emb_ln_b"]), P(ws["gain"]), Bn, st)
+            if taps is not None:
+                taps["Z0"], taps["G"] = xa.clone(), ws["gain"].clone()
+
+            rows = Bn * T * F_
+            for i in range(self.n_blocks):
+                bp = pk["blocks"][i]
+                bs = state["gridnet_bufs"][f"buf{i}"]
+                # intra: LN + BiLSTM over frequency -> Linear(128->64) + residual
+                lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra_w"]),
+                         P(bp["intra_b"]), P(hbuf), Bn * T, st)
+                lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
+                         2 * H_, st)
+                # inter: LN + causal LSTM over time with carried state -> Linear(64->64) + residual
+                h0, c0 = c32(bs["h0"]), c32(bs["c0"])
+                hN, cN = new(h0), new(c0)
+                lib.call("lh_ln_lstm_inter", P(xb), P(bp["inter_ln_w"]), P(bp["inter_ln_b"]), P(bp["inter_w"]),
+                         P(bp["inter_b"]), P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, st)
+                lib.call("lh_linear_res", P(hbuf), P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(xb), P(xc), rows,
+                         H_, st)
+                # attention: history rows in, Q/K/V, local attention (head merge fused), projection + LN + residual
+                ws["kx"][:, :hist, :self.E * F_].copy_(bs["K_buf"])
+                ws["vx"][:, :hist].copy_(bs["V_buf"])
+                lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
+                         P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
+                         P(ws["kx"]), P(ws["vx"]), Bn, T, st)
+                lib.call("lh_local_attn", P(ws["q"]), P(ws["kx"]), P(ws["vx"]), P(xb), Bn, T, st)
+                gain = ws["gain"] if (i == 0 and self.n_blocks > 1) else None   # `batch * embed` before block 1
+                lib.call("lh_proj_ln_res", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
+                         P(bp["proj_ln_w"]), P(bp["proj_ln_b"]), P(xc), P(gain) if gain is not None else None, P(xa),
+                         Bn, T, st)
+                bs["h0"], bs["c0"] = hN, cN
+                bs["K_buf"] = ws["kx"][:, T:T + hist, :self.E * F_].contiguous()
+                bs["V_buf"] = ws["vx"][:, T:T + hist].contiguous()
+                if taps is not None:
+                    taps[f"blocks.{i}.Y2"] = xc.clone()
+                    taps[f"blocks.{i}.Q"] = ws["q"][:, :, :self.E * F_].clone()
+                    taps[f"blocks.{i}.K"] = ws["kx"][:, hist:, :self.E * F_].clone()
+                    taps[f"blocks.{i}.V"] = ws["vx"][:, hist:].clone()
+                    taps[f"blocks.{i}.out"] = xa.clone()
+
+            dec_in, ist_in = c32(state["deconv_buf"]), c32(state["istft_buf"])
+            dec_out, ist_out = new(dec_in), new(ist_in)
+            y = torch.empty(Bn, self.n_srcs, hop * T, device=dev, dtype=torch.float32)
+            lib.call("lh_deconv_istft", P(xa), P(dec_in), P(dec_out), P(ist_in), P(ist_out), P(pk["deconv_w"]),
+                     P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), Bn, T, st)
+            state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
+        return y, state

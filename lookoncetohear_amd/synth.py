@@ -30,7 +30,7 @@ def _source(rs: np.random.RandomState, n: int) -> np.ndarray:
     env = 0.5 * (1 + np.sin(2 * np.pi * rs.uniform(3, 5) * t + rs.uniform(0, 6.28)))
     gate = (rs.rand(int(np.ceil(n / 4000)) + 1) > 0.25).astype(np.float64)
     gate = np.repeat(gate, 4000)[:n]
-    gate = np.convolve(gate, np.ones(400) / 400, mode="same")
+    gate = np.convolve(gate, np.ones(400) / 400, mode="same")[:n]
     return sig * env * gate
 
 

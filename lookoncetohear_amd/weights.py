@@ -1,0 +1,83 @@
+"""Packing of reference-named parameters (SURVEY.md §8b checkpoint surface) into the device images the
+kernels expect.  Pure index shuffles (torch ops on whatever device the parameters live on), done once per
+parameter version; the arithmetic stays in the HIP kernels.
+
+MFMA B-operand image (v_mfma_f32_16x16x4_f32): for an output-column tile `nt` and k-step `ks`, lane `l`
+holds  W[n = nt*16 + (l & 15)][k = (l >> 4) * (K/4) + ks]  — the k axis is split into four contiguous chunks,
+one per 16-lane group, so the matching A operand is 32 (or 16) contiguous floats per lane in LDS.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def pack_linear(w: torch.Tensor) -> torch.Tensor:
+    """w [N, K] (nn.Linear weight) -> [N/16, K/4, 64] fp32 B-operand image."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 16 == 0
+    lane = torch.arange(64, device=w.device)
+    n = torch.arange(N // 16, device=w.device)[:, None, None] * 16 + (lane & 15)[None, None, :]
+    k = (lane >> 4)[None, None, :] * (K // 4) + torch.arange(K // 4, device=w.device)[None, :, None]
+    return w[n, k].contiguous().float()
+
+
+def pack_lstm(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """w_ih [4H, I], w_hh [4H, H] (gate order i,f,g,o) -> [4 waves, 4 gates, 32 ksteps, 64 lanes].
+
+    Wave `w` owns hidden units 16w..16w+15 of every gate: column tile (w, g) = rows g*H + 16w + (l & 15) of
+    the concatenated [W_ih | W_hh]; k = (l >> 4) * 32 + ks over the 128 inputs [x(64) | h(64)].
+    """
+    H = w_hh.shape[1]
+    assert H == 64 and tuple(w_ih.shape) == (4 * H, 64)
+    wcat = torch.cat([w_ih, w_hh], dim=1)                       # [256, 128]
+    lane = torch.arange(64, device=wcat.device)
+    wave = torch.arange(4, device=wcat.device)[:, None, None, None]
+    gate = torch.arange(4, device=wcat.device)[None, :, None, None]
+    ks = torch.arange(32, device=wcat.device)[None, None, :, None]
+    col = gate * H + wave * 16 + (lane & 15)[None, None, None, :]
+    k = (lane >> 4)[None, None, None, :] * 32 + ks
+    return wcat[col, k].contiguous().float()
+
+
+def pack_block(sd: dict, pre: str) -> dict:
+    g = lambda k: sd[pre + k].detach()
+    out = {}
+    out["intra_ln_w"], out["intra_ln_b"] = g("intra_norm.norm.weight"), g("intra_norm.norm.bias")
+    out["intra_w"] = torch.stack([pack_lstm(g("intra_rnn.weight_ih_l0"), g("intra_rnn.weight_hh_l0")),
+                                  pack_lstm(g("intra_rnn.weight_ih_l0_reverse"), g("intra_rnn.weight_hh_l0_reverse"))])
+    out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
+                                  g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
+    out["intra_lin_w"], out["intra_lin_b"] = pack_linear(g("intra_linear.weight")), g("intra_linear.bias")
+    out["inter_ln_w"], out["inter_ln_b"] = g("inter_norm.norm.weight"), g("inter_norm.norm.bias")
+    out["inter_w"] = pack_lstm(g("inter_rnn.weight_ih_l0"), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
+    out["inter_b"] = g("inter_rnn.bias_ih_l0") + g("inter_rnn.bias_hh_l0")
+    out["inter_lin_w"], out["inter_lin_b"] = pack_linear(g("inter_linear.weight")), g("inter_linear.bias")
+    out["qkv_w"] = pack_linear(torch.cat([g("attn_conv_Q.0.weight"), g("attn_conv_K.0.weight"),
+                                          g("attn_conv_V.0.weight")], 0))
+    out["qkv_b"] = torch.cat([g("attn_conv_Q.0.bias"), g("attn_conv_K.0.bias"), g("attn_conv_V.0.bias")])
+    out["qkv_slopes"] = torch.cat([g("attn_conv_Q.1.weight"), g("attn_conv_K.1.weight"), g("attn_conv_V.1.weight")])
+    for nm in "QKV":
+        out[f"ln{nm.lower()}_w"] = g(f"attn_conv_{nm}.3.norm.weight")
+        out[f"ln{nm.lower()}_b"] = g(f"attn_conv_{nm}.3.norm.bias")
+    out["proj_w"], out["proj_b"] = pack_linear(g("attn_concat_proj.0.weight")), g("attn_concat_proj.0.bias")
+    out["proj_slope"] = g("attn_concat_proj.1.weight")
+    out["proj_ln_w"], out["proj_ln_b"] = g("attn_concat_proj.3.norm.weight"), g("attn_concat_proj.3.norm.bias")
+    return {k: v.contiguous().float() for k, v in out.items()}
+
+
+def pack_all(sd: dict, n_blocks: int, prefix: str = "tfgridnet.") -> dict:
+    """sd: state-dict-like mapping with the reference names -> dict of packed fp32 tensors."""
+    g = lambda k: sd[prefix + k].detach()
+    out = {
+        "wfb_t": g("enc.filterbank._filters")[:, 0].t(),                     # [192, 194]
+        "wfb_dec": g("dec.filterbank._filters")[:, 0],                       # [194, 192]
+        "conv_w": g("conv.0.weight").permute(1, 2, 3, 0).reshape(36, -1),    # [(ch,kt,kf), o]
+        "conv_b": g("conv.0.bias"),
+        "emb_w": g("embed_to_feats_proj.0.weight"), "emb_b": g("embed_to_feats_proj.0.bias"),
+        "emb_ln_w": g("embed_to_feats_proj.1.weight"), "emb_ln_b": g("embed_to_feats_proj.1.bias"),
+        "deconv_w": g("deconv.weight").permute(1, 2, 3, 0),                  # [o, kt, kf, c]
+        "deconv_b": g("deconv.bias"),
+    }
+    out = {k: v.contiguous().float() for k, v in out.items()}
+    out["blocks"] = [pack_block(sd, f"{prefix}blocks.{i}.") for i in range(n_blocks)]
+    return out

@@ -1,0 +1,30 @@
+"""TEST INFRASTRUCTURE: compiles the unmodified kernel sources as host C++ against tests/hipemu/include
+(see that header).  Output: tests/hipemu/_build/liblookonce_emu.so — used by `-m "not gpu"` tests only."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "lookoncetohear_amd", "csrc")
+OUT = os.path.join(HERE, "_build", "liblookonce_emu.so")
+SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip"]
+
+
+def build_emu(force=False):
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        cxx = "clang++"
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "lh_common.h"),
+                                                       os.path.join(HERE, "include", "hip", "hip_runtime.h"),
+                                                       os.path.join(ROOT, "include", "lookonce_hip.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
+           "-I", os.path.join(HERE, "include"), *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_emu(force=True))
