@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — the headline benchmark of BASELINE.json on the MI355X-native separator path.
+
+A "step" is one pass of the hot path (`Net.forward`: STFT -> 3 GridNet blocks -> iSTFT, state init included,
+exactly what reference src/ts_hear_test.py:138 executes per batch) over one per-GPU batch of synthetic 5 s,
+16 kHz binaural mixtures already resident in HBM, followed by the eval loop's metric sums (SI-SNRi etc.,
+reference src/ts_hear_test.py:144-146) and — for N > 1 — the one real exchange step of the sharded eval,
+an RCCL all-reduce of those 4 sums.  Workload at N=1: BASELINE.json configs[2] ("1xMI355X batch=32 offline
+5 s clips"); N>1 shards utterances (weak scaling: 32 per GPU, configs[3] is 8 x 32 = 256).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (largest share of GPU time in the
+timed region), measured live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a port
+of the reference algorithm, oracle/tfgridnet_oracle.py) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES_PER_CLIP = 625                 # 5 s @ 16 kHz, hop 128
+CLIP_SECONDS = 5.0
+FLOPS_PER_CLIP = 46.67e9              # SURVEY.md §8(d) algorithmic FLOPs
+BYTES_PER_CLIP = 614.3e6              # SURVEY.md §8(d) algorithmic bytes (fp32, five fused stages per block)
+WEIGHT_BYTES = 8.15e6
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+# algorithmic work per LAUNCH and per clip of each kernel (FLOPs, bytes) — SURVEY.md §8(a)/(d), DESIGN.md §4
+KERNEL_WORK = {
+    "lh_ln_lstm_intra": dict(flops=625 * 97 * 2 * 2 * 128 * 256, bytes=(1 + 2) * 15.52e6, bound="mfma"),
+    "lh_ln_lstm_inter": dict(flops=625 * 97 * 2 * 128 * 256, bytes=(1 + 1) * 15.52e6, bound="mfma"),
+    "lh_linear_res": dict(flops=625 * 97 * 2 * 96 * 64, bytes=(1.5 + 1 + 1) * 15.52e6, bound="hbm"),   # avg K=96
+    "lh_qkv_proj_ln": dict(flops=625 * 97 * 2 * 64 * 112, bytes=15.52e6 + 2 * 5.82e6 + 15.52e6, bound="hbm"),
+    "lh_local_attn": dict(flops=4 * 625 * 50 * 2 * (582 + 1552), bytes=2 * 5.82e6 + 2 * 15.52e6, bound="hbm"),
+    "lh_proj_ln_res": dict(flops=625 * 97 * 2 * 64 * 64, bytes=3 * 15.52e6, bound="hbm"),
+    "lh_stft_conv_in": dict(flops=0.37e9, bytes=16.16e6, bound="hbm"),
+    "lh_deconv_istft": dict(flops=0.37e9, bytes=16.16e6, bound="hbm"),
+    "lh_embed_proj_ln": dict(flops=3.2e6, bytes=6.4e6, bound="hbm"),
+}
+
+
+def cpu_baseline(sample_clips=4, repeats=2):
+    """CPU oracle on the host cores: bounded sample of the same workload (micro-batch of <= 4 utterances, the
+    reference's own eval batch size, src/ts_hear_test.py:121)."""
+    from lookoncetohear_amd import synth
+    from oracle import tfgridnet_oracle as O
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    cfg = O.Cfg(**O.TSH_PARAMS)
+    sd = O.synthetic_state_dict(cfg, 0)
+    d = synth.batch(list(range(sample_clips)), 80000)
+    O.forward(cfg, sd, d["mixture"][:1, :, :16000], d["embedding_gt"][:1], fast_lstm=True)     # warm-up
+    best = float("inf")
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        O.forward(cfg, sd, d["mixture"], d["embedding_gt"], fast_lstm=True)
+        best = min(best, time.perf_counter() - t0)
+    return dict(value=sample_clips * FRAMES_PER_CLIP / best, unit="frames/s", cores=cores, kind="port",
+                rtf=best / (sample_clips * CLIP_SECONDS),
+                sample=f"{sample_clips} x 5 s clips, one micro-batch, best of {repeats}, torch CPU fp32 oracle "
+                       f"(oracle/tfgridnet_oracle.py, fused CPU LSTM), {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE configs[2] = 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)     # RCCL over xGMI
+
+    from lookoncetohear_amd import synth, _cabi
+    from lookoncetohear_amd.net import Net
+    from lookoncetohear_amd.metrics import metric_sums
+    from oracle import tfgridnet_oracle as O
+    _cabi.load()                                                    # fail loudly if the HIP extension is missing
+
+    cfg = O.Cfg(**O.TSH_PARAMS)
+    net = Net(**O.TSH_PARAMS).eval()
+    net.load_state_dict(O.synthetic_state_dict(cfg, 0), strict=True)    # random-init weights of the tsh.json arch
+    net = net.to(dev)
+
+    B = args.batch
+    # utterance sharding: rank r owns utterances r*B .. r*B+B-1 (seeded by index -> rank-count invariant union);
+    # 8 distinct utterances are synthesised per rank and tiled to B to keep set-up time bounded
+    uniq = min(B, 8)
+    d = synth.batch([rank * B + i for i in range(uniq)], 80000)
+    rep = (B + uniq - 1) // uniq
+    mix = d["mixture"].repeat(rep, 1, 1)[:B].contiguous().to(dev)
+    tgt = d["target"].repeat(rep, 1, 1)[:B].contiguous().to(dev)
+    emb = d["embedding_gt"].repeat(rep, 1, 1)[:B].contiguous().to(dev)
+
+    def step():
+        y = net(mix, emb)
+        sums = metric_sums(y, mix, tgt, emb[:, 0], emb[:, 0])       # [sum si_snr_i, sum out_sisnr, sum cos, n] fp64
+        if dist is not None:
+            dist.all_reduce(sums)                                   # the path's only exchange step (32 B)
+        return y, sums
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        net._prof = []
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y, sums = step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof, net._prof = net._prof, None
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # per-kernel HIP-event durations over the timed region (this rank)
+    per = {}
+    for name, e0, e1 in prof:
+        per.setdefault(name, []).append(e0.elapsed_time(e1))
+    kern = {k: dict(launches=len(v), total_ms=sum(v), avg_ms=sum(v) / len(v)) for k, v in per.items()}
+    gpu_ms = sum(v["total_ms"] for v in kern.values())
+
+    if rank == 0:
+        total_clips = world * B * args.steps
+        value = total_clips * FRAMES_PER_CLIP / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        dom = max(kern, key=lambda k: kern[k]["total_ms"])
+        w = KERNEL_WORK[dom]
+        if w["bound"] == "mfma":
+            ach = w["flops"] * B / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+            roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None)
+        else:
+            ach = w["bytes"] * B / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
+                        frac=ach / PEAK_HBM_GBS, traffic=None)
+        roof["avg_launch_ms"] = kern[dom]["avg_ms"]
+        roof["share_of_gpu_time"] = kern[dom]["total_ms"] / gpu_ms
+        out = {
+            "metric": "frames_per_sec (5 s 16 kHz binaural clips, 625 STFT frames each, offline forward)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "rtf": elapsed / (total_clips * CLIP_SECONDS),
+            "config": {"workload": f"BASELINE configs[2]: {B} x 5 s 16 kHz binaural clips per GPU, offline forward "
+                                   f"(configs/tsh.json separator, random-init weights)",
+                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"utterance-dp{world}"},
+            "whole_path": {"algorithmic_tflops": FLOPS_PER_CLIP * total_clips / elapsed / 1e12,
+                           "algorithmic_hbm_gbs": (BYTES_PER_CLIP * B + WEIGHT_BYTES) * world * args.steps / elapsed / 1e9,
+                           "frac_fp32_mfma_peak": FLOPS_PER_CLIP * total_clips / elapsed / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+                           "frac_hbm_peak": (BYTES_PER_CLIP * B + WEIGHT_BYTES) * world * args.steps / elapsed / 1e9 / (PEAK_HBM_GBS * world)},
+            "roofline": roof,
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"])},
+            "metric_sums": [float(v) for v in sums.tolist()],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""Utterance-sharded evaluation, shaped like the reference eval driver (reference src/ts_hear_test.py:93-166)
+with its hot loop (:124-150) kept: for each batch  embedding -> model(mixture, embedding) -> SI-SNR / SI-SNRi /
+cosine similarity per utterance.  The reference is single-process; here utterances are independent (eval mode,
+per-sample norms, per-utterance state), so they are partitioned `idx % world == rank` over one process per GPU
+and the only exchange step is ONE all-reduce of `[sum si_snr_i, sum output_sisnr, sum embedding_sim, n]`
+(RCCL over xGMI on the GPUs, gloo in the CPU tests) — SURVEY.md §8(e).  No data-path collective.
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, List, Optional
+
+import torch
+
+from .metrics import metric_sums, per_utterance
+
+
+def shard_indices(n_utts: int, rank: int, world: int) -> List[int]:
+    """Strided split; inputs are seeded by utterance index so the union is independent of `world`."""
+    return list(range(rank, n_utts, world))
+
+
+def evaluate(model: Callable, data_fn: Callable[[List[int]], dict], n_utts: int, batch_size: int = 4,
+             rank: int = 0, world: int = 1, device="cpu", dist=None, enroll_model: Optional[Callable] = None):
+    """Returns (mean si_snr_i, mean output_sisnr, mean embedding_sim, n) over ALL ranks, plus this rank's rows.
+
+    `model(mixture [B,2,N], embedding [B,1,256]) -> [B,2,N]` is the separator (`Net.forward`);
+    `data_fn(indices)` returns the dict of reference dataset fields (mixture, target, embedding_gt[, enrollments]).
+    """
+    mine = shard_indices(n_utts, rank, world)
+    total = torch.zeros(4, dtype=torch.float64, device=device)
+    rows = []
+    with torch.no_grad():
+        for s in range(0, len(mine), batch_size):
+            idx = mine[s:s + batch_size]
+            d = data_fn(idx)
+            mixture = d["mixture"].to(device)
+            target = d["target"].to(device)
+            emb_gt = d["embedding_gt"].to(device)
+            if enroll_model is not None:                     # ts_hear_test.py:132-135
+                embedding = enroll_model(d["enrollments"].to(device)).unsqueeze(1)
+            else:
+                embedding = emb_gt                           # :137
+            outputs = model(mixture, embedding)              # :138  <- the hot path
+            total += metric_sums(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
+            o, i, c = per_utterance(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
+            rows += [dict(idx=k, output_sisnr=float(a), si_snr_i=float(b), embedding_sim=float(e))
+                     for k, a, b, e in zip(idx, o.tolist(), i.tolist(), c.tolist())]
+    if dist is not None and world > 1:
+        dist.all_reduce(total)                               # sum over ranks, 32 bytes
+    n = max(float(total[3].item()), 1.0)
+    return dict(si_snr_i=float(total[0].item()) / n, output_sisnr=float(total[1].item()) / n,
+                embedding_sim=float(total[2].item()) / n, n=int(total[3].item())), rows

@@ -1,0 +1,36 @@
+"""Eval metrics of the reference test loop (reference src/ts_hear_test.py:140-146), restated on torch tensors
+so they run on the device that holds the separator output (no `outputs.cpu()` round trip).
+
+`scale_invariant_signal_noise_ratio` (torchmetrics, absent here) = zero-mean SI-SDR:
+    alpha = (<p,t> + eps) / (<t,t> + eps);  10 log10((|alpha t|^2 + eps) / (|alpha t - p|^2 + eps)), eps = fp32 eps.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def si_snr(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    eps = torch.finfo(pred.dtype).eps
+    pred = pred - pred.mean(-1, keepdim=True)
+    target = target - target.mean(-1, keepdim=True)
+    alpha = ((pred * target).sum(-1, keepdim=True) + eps) / ((target * target).sum(-1, keepdim=True) + eps)
+    scaled = alpha * target
+    noise = scaled - pred
+    return 10.0 * torch.log10(((scaled * scaled).sum(-1) + eps) / ((noise * noise).sum(-1) + eps))
+
+
+def per_utterance(outputs, mixture, target, embedding, embedding_gt):
+    """Rows of the reference CSV (ts_hear_test.py:149-151): output_sisnr, si_snr_i, embedding_sim — each [B]."""
+    out_sisnr = si_snr(outputs, target)                                   # [B, 2]
+    snr_i = out_sisnr - si_snr(mixture, target)
+    return (out_sisnr.mean(dim=1), snr_i.reshape(snr_i.shape[0], -1).mean(dim=1),
+            F.cosine_similarity(embedding, embedding_gt, dim=-1))
+
+
+def metric_sums(outputs, mixture, target, embedding, embedding_gt) -> torch.Tensor:
+    """[sum si_snr_i, sum output_sisnr, sum embedding_sim, n] as fp64 on the outputs' device — the 32-byte
+    payload of the sharded eval's single all-reduce."""
+    o, i, c = per_utterance(outputs, mixture, target, embedding, embedding_gt)
+    n = torch.tensor(float(outputs.shape[0]), device=outputs.device, dtype=torch.float64)
+    return torch.stack([i.double().sum(), o.double().sum(), c.double().sum(), n])

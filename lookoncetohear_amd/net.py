@@ -147,6 +147,7 @@ class Net(nn.Module):
         self._ws: Dict[tuple, dict] = {}
         self._lib_override = None          # TEST HOOK ONLY (tests/hipemu): never set on the product path
         self._debug_taps: Optional[dict] = None
+        self._prof: Optional[list] = None  # bench.py: list of (kernel tag, start event, end event) per launch
 
     # ------------------------------------------------------------------------------------------------
     # reference API
@@ -247,6 +248,20 @@ class Net(nn.Module):
             c32 = lambda t: t.contiguous().float()
             taps = self._debug_taps
             xa, xb, xc, hbuf = ws["xa"], ws["xb"], ws["xc"], ws["hbuf"]
+            prof = self._prof if x.is_cuda else None
+
+            class _Timed:                       # HIP events on the launch stream around each C-ABI call
+                @staticmethod
+                def call(name, *args):
+                    if prof is None:
+                        return lib_.call(name, *args)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    lib_.call(name, *args)
+                    e1.record()
+                    prof.append((name, e0, e1))
+
+            lib_, lib = lib, _Timed
 
             conv_in = c32(state["conv_buf"]); conv_out = new(conv_in)
             lib.call("lh_stft_conv_in", P(x), P(conv_in), P(conv_out), P(pk["wfb_t"]), P(pk["conv_w"]),
