@@ -49,12 +49,13 @@ KERNEL_WORK = {
 }
 
 
-def cpu_baseline(sample_clips=4, repeats=2):
+def cpu_baseline(sample_clips=4, repeats=2, max_threads=32):
     """CPU oracle on the host cores: bounded sample of the same workload (micro-batch of <= 4 utterances, the
-    reference's own eval batch size, src/ts_hear_test.py:121)."""
+    reference's own eval batch size, src/ts_hear_test.py:121).  Threads = min(host cores, 32): the step-serial
+    LSTM/attention ops of this model do not scale past a few dozen threads (oversubscription only adds barriers)."""
     from lookoncetohear_amd import synth
     from oracle import tfgridnet_oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = min(len(os.sched_getaffinity(0)), max_threads)
     torch.set_num_threads(cores)
     cfg = O.Cfg(**O.TSH_PARAMS)
     sd = O.synthetic_state_dict(cfg, 0)
@@ -67,8 +68,23 @@ def cpu_baseline(sample_clips=4, repeats=2):
         best = min(best, time.perf_counter() - t0)
     return dict(value=sample_clips * FRAMES_PER_CLIP / best, unit="frames/s", cores=cores, kind="port",
                 rtf=best / (sample_clips * CLIP_SECONDS),
+                host_cores=len(os.sched_getaffinity(0)),
                 sample=f"{sample_clips} x 5 s clips, one micro-batch, best of {repeats}, torch CPU fp32 oracle "
                        f"(oracle/tfgridnet_oracle.py, fused CPU LSTM), {cores} threads")
+
+
+def cpu_baseline_subprocess(timeout_s=240):
+    """Runs cpu_baseline() in a child process with a hard time limit so the GPU measurement can never hang on it."""
+    import subprocess
+    code = "import json, bench; print('CPUBASE ' + json.dumps(bench.cpu_baseline()))"
+    try:
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+        for line in out.stdout.splitlines():
+            if line.startswith("CPUBASE "):
+                return json.loads(line[len("CPUBASE "):])
+        return dict(value=None, unit="frames/s", cores=0, kind="port", sample="failed: " + out.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="frames/s", cores=0, kind="port", sample=f"timed out after {timeout_s} s")
 
 
 def main():
@@ -120,9 +136,13 @@ def main():
             dist.all_reduce(sums)                                   # the path's only exchange step (32 B)
         return y, sums
 
+    log = lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)
+    log(f"inputs resident: {B} clips on {dev}")
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
+        torch.cuda.synchronize()
+        log("warm-up done")
         net._prof = []
         if dist is not None:
             dist.barrier()
@@ -135,6 +155,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         prof, net._prof = net._prof, None
+    log(f"timed region: {elapsed * 1e3 / args.steps:.3f} ms/step")
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -181,7 +202,7 @@ def main():
             "metric_sums": [float(v) for v in sums.tolist()],
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline_subprocess()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

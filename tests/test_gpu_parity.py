@@ -94,16 +94,21 @@ def test_golden_full_clip_and_stages(net, golden, oracle_cfg_sd):
 
 def test_batch32_invariance_and_oracle(net, oracle_cfg_sd):
     """BASELINE config 3 size (B=32 x 5 s): utterances are independent, so every row of the batched run must
-    equal the same utterance run alone (bit-exact: identical fmaf chains), and two rows are checked against
-    the CPU oracle at full length."""
+    equal the same utterance run alone (different tile shapes / kernel instantiations, so equal up to fp32
+    contraction order: 2e-5), rows of a repeated run must be bit-identical (no races), and two rows are checked
+    against the CPU oracle at full length."""
     cfg, sd = oracle_cfg_sd
     idx = list(range(100, 132))
     d = synth.batch(idx, 80000)
     y = net(d["mixture"].to(DEV), d["embedding_gt"].to(DEV))
     assert tuple(y.shape) == (32, 2, 80000) and torch.isfinite(y).all()
+    y_again = net(d["mixture"].to(DEV), d["embedding_gt"].to(DEV))
+    assert torch.equal(y, y_again)                    # deterministic: no races, no atomics
     for r in (0, 17, 31):
         y1 = net(d["mixture"][r:r + 1].to(DEV), d["embedding_gt"][r:r + 1].to(DEV))
-        assert torch.equal(y1[0], y[r]), r
+        e = _err(y1[0], y[r].cpu())
+        print("batch-of-1 vs row", r, e)
+        assert e < 2e-5, r
     for r in (5, 31):
         yo = O.forward(cfg, sd, d["mixture"][r:r + 1], d["embedding_gt"][r:r + 1], fast_lstm=True)
         e = _err(y[r:r + 1], yo)
