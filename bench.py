@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE configs[2] = 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", default=None, choices=["f32", "f16x3"], help="override Net.gemm_mode (A/B runs)")
+    ap.add_argument("--tune", default="", help="comma list key=value for lh_set_tuning (A/B runs), e.g. 0=2,1=1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +120,11 @@ def main():
     net = Net(**O.TSH_PARAMS).eval()
     net.load_state_dict(O.synthetic_state_dict(cfg, 0), strict=True)    # random-init weights of the tsh.json arch
     net = net.to(dev)
+    if args.gemm:
+        net.gemm_mode = args.gemm
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        assert _cabi.load().raw("lh_set_tuning")(int(k), int(v)) == 0
 
     B = args.batch
     # utterance sharding: rank r owns utterances r*B .. r*B+B-1 (seeded by index -> rank-count invariant union);
@@ -192,7 +199,8 @@ def main():
             "rtf": elapsed / (total_clips * CLIP_SECONDS),
             "config": {"workload": f"BASELINE configs[2]: {B} x 5 s 16 kHz binaural clips per GPU, offline forward "
                                    f"(configs/tsh.json separator, random-init weights)",
-                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"utterance-dp{world}"},
+                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"utterance-dp{world}",
+                       "gemm_mode": net.gemm_mode, "tune": args.tune},
             "whole_path": {"algorithmic_tflops": FLOPS_PER_CLIP * total_clips / elapsed / 1e12,
                            "algorithmic_hbm_gbs": (BYTES_PER_CLIP * B + WEIGHT_BYTES) * world * args.steps / elapsed / 1e9,
                            "frac_fp32_mfma_peak": FLOPS_PER_CLIP * total_clips / elapsed / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),

@@ -31,8 +31,19 @@ enum {
     LH_ERR_LAUNCH = 3       /* hipGetLastError() != hipSuccess after the launch */
 };
 
+/* Contraction arithmetic of the recurrent kernels (argument `mode`):
+ *   LH_GEMM_F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32); w_pk = fp32 image  [dirs][4][4][32][64]
+ *   LH_GEMM_F16X3 split precision: each fp32 operand = fp16 hi + 2^-11 * fp16 lo, three fp16 MFMAs
+ *                 (hi*hi, hi*lo, lo*hi) accumulated in fp32 (~22 mantissa bits);
+ *                 w_pk = fp16 image [dirs][4 waves][4 gates][4 ksteps][64 lanes][hi 8 | lo 8]  */
+enum { LH_GEMM_F32 = 0, LH_GEMM_F16X3 = 1 };
+
 /* ABI version of this header; bumped on any signature change. */
 int lh_abi_version(void);
+
+/* Launch-shape tuning knobs (benchmark A/B only; 0 = automatic): key 0 = sequences-per-workgroup/16 of the
+ * intra LSTM, key 1 = same for the inter LSTM. */
+int lh_set_tuning(int key, int value);
 
 /* Validates model_params (reference net.py:21-49 / configs/tsh.json:5-19) against the compiled constants. */
 int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unused, int lstm_hidden,
@@ -52,10 +63,11 @@ int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* conv_buf_ou
 
 /* A.2  speaker gain  g = LayerNorm_6208(W e + b)  stored f-major:  gain[b][f][c] = g[b][c*97+f].
  * Replaces tfgridnet_causal.py:247-248 (embed_to_feats_proj + reshape).
- *   emb [B][256]; w [6208][256]; bias, ln_w, ln_b [6208]; gain [B][97][64] out
+ *   emb [B][256]; w [6208][256]; bias, ln_w, ln_b [6208]; scratch [B][6208] (raw projection, workspace);
+ *   gain [B][97][64] out
  */
 int lh_embed_proj_ln(const float* emb, const float* w, const float* bias, const float* ln_w, const float* ln_b,
-                     float* gain, int B, lh_stream_t stream);
+                     float* scratch, float* gain, int B, lh_stream_t stream);
 
 /* A.3.1  intra-frame path: LayerNorm(C) -> BiLSTM over frequency (zero initial state) ; hidden states only.
  * Replaces tfgridnet_causal.py:505-512 (intra_norm, intra_rnn).
@@ -65,16 +77,16 @@ int lh_embed_proj_ln(const float* emb, const float* w, const float* bias, const 
  *          lookoncetohear_amd/weights.py: pack_lstm);  b_sum [2][256] = bias_ih + bias_hh
  *   h_out  [B*T*97][128]   (forward hidden in cols 0..63, reverse in 64..127)
  */
-int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* ln_b, const float* w_pk, const float* b_sum,
-                     float* h_out, int n_frames /* B*T */, lh_stream_t stream);
+int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* ln_b, const void* w_pk, const float* b_sum,
+                     float* h_out, int n_frames /* B*T */, int mode, lh_stream_t stream);
 
 /* A.3.2  inter-frame path: LayerNorm(C) -> causal LSTM over time with carried state ; hidden states only.
  * Replaces tfgridnet_causal.py:521-532 (inter_norm, transpose/reshape to [B*F,T,C], inter_rnn, h0/c0 in/out).
  *   x [B][T][97][64]; h0,c0,hN,cN [B*97][64] (sequence index b*97+f); w_pk [1][4][4][32][64]; b_sum [256]
  *   h_out [B*T*97][64] in the same (b,t,f) row order as x
  */
-int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const float* w_pk, const float* b_sum,
-                     const float* h0, const float* c0, float* hN, float* cN, float* h_out, int B, int T,
+int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const void* w_pk, const float* b_sum,
+                     const float* h0, const float* c0, float* hN, float* cN, float* h_out, int B, int T, int mode,
                      lh_stream_t stream);
 
 /* Row-wise Linear(K->64) + bias + residual:  out[r][:] = res[r][:] + W h[r][:] + b.

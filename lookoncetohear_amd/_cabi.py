@@ -11,7 +11,7 @@ from ctypes import c_int, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P, _I = c_void_p, c_int
 # name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
@@ -19,9 +19,10 @@ SIGNATURES = {
     "lh_abi_version": [],
     "lh_check_config": [_I] * 10,
     "lh_stft_conv_in": [_P] * 7 + [_I] * 3 + [_P],
-    "lh_embed_proj_ln": [_P] * 6 + [_I, _P],
-    "lh_ln_lstm_intra": [_P] * 6 + [_I, _P],
-    "lh_ln_lstm_inter": [_P] * 10 + [_I, _I, _P],
+    "lh_embed_proj_ln": [_P] * 7 + [_I, _P],
+    "lh_set_tuning": [_I, _I],
+    "lh_ln_lstm_intra": [_P] * 6 + [_I, _I, _P],
+    "lh_ln_lstm_inter": [_P] * 10 + [_I, _I, _I, _P],
     "lh_linear_res": [_P] * 5 + [_I, _I, _P],
     "lh_qkv_proj_ln": [_P] * 13 + [_I, _I, _P],
     "lh_local_attn": [_P] * 4 + [_I, _I, _P],

@@ -96,28 +96,44 @@ __global__ void __launch_bounds__(256) k_stft_conv_in(const float* __restrict__ 
     }
 }
 
-// grid B, block 256
-__global__ void __launch_bounds__(256) k_embed_proj_ln(const float* __restrict__ emb, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, const float* __restrict__ lnw,
-                                                        const float* __restrict__ lnb, float* __restrict__ gain) {
-    constexpr int N = C * NF;   // 6208
-    __shared__ float es[SPK];
-    __shared__ float vals[N];
-    __shared__ float red[4];
+// speaker-gain projection, row-parallel: grid (ceil(6208/32), ceil(B/8)); each workgroup streams 32 rows of W once
+// and applies them to 8 utterances (W is read from HBM once per launch, re-used from L2 across the batch groups)
+constexpr int EP_ROWS = 32, EP_NB = 8;
+__global__ void __launch_bounds__(256) k_embed_proj(const float* __restrict__ emb, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ raw, int B) {
+    constexpr int N = C * NF;
+    __shared__ __attribute__((aligned(16))) float es[EP_NB][SPK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    es[tid] = emb[b * SPK + tid];
-    __syncthreads();
-    const float4 e4 = *reinterpret_cast<const float4*>(&es[lane * 4]);
-    for (int r = wave; r < N; r += 4) {
-        const float4 w4 = *reinterpret_cast<const float4*>(&w[(long)r * SPK + lane * 4]);
-        float s = w4.x * e4.x + w4.y * e4.y + w4.z * e4.z + w4.w * e4.w;
-        s = wave_sum(s);
-        if (lane == 0) vals[r] = s + bias[r];
+    const int b0 = blockIdx.y * EP_NB;
+    for (int i = tid; i < EP_NB * SPK; i += 256) {
+        const int bb = min(b0 + i / SPK, B - 1);
+        es[i / SPK][i % SPK] = emb[(long)bb * SPK + (i % SPK)];
     }
     __syncthreads();
+    for (int rr = wave; rr < EP_ROWS; rr += 4) {
+        const int r = blockIdx.x * EP_ROWS + rr;
+        if (r >= N) break;
+        const float4 w4 = *reinterpret_cast<const float4*>(&w[(long)r * SPK + lane * 4]);
+        const float bz = bias[r];
+#pragma unroll
+        for (int j = 0; j < EP_NB; ++j) {
+            const float4 e4 = *reinterpret_cast<const float4*>(&es[j][lane * 4]);
+            float s = wave_sum(w4.x * e4.x + w4.y * e4.y + w4.z * e4.z + w4.w * e4.w);
+            if (lane == 0 && b0 + j < B) raw[(long)(b0 + j) * N + r] = s + bz;
+        }
+    }
+}
+
+// LayerNorm over the 6208 projected values of one utterance + (c,f) -> (f,c) transpose; grid B
+__global__ void __launch_bounds__(256) k_embed_ln(const float* __restrict__ raw, const float* __restrict__ lnw,
+                                                   const float* __restrict__ lnb, float* __restrict__ gain) {
+    constexpr int N = C * NF;   // 6208
+    __shared__ float vals[N];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
     float s = 0.0f;
-    for (int i = tid; i < N; i += 256) s += vals[i];
+    for (int i = tid; i < N; i += 256) { const float v = raw[(long)b * N + i]; vals[i] = v; s += v; }
     const float mean = block_sum_256(s, red) * (1.0f / N);
     float v = 0.0f;
     for (int i = tid; i < N; i += 256) { float d = vals[i] - mean; v += d * d; }
@@ -143,14 +159,16 @@ extern "C" int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* 
 }
 
 extern "C" int lh_embed_proj_ln(const float* emb, const float* w, const float* bias, const float* ln_w,
-                                const float* ln_b, float* gain, int B, lh_stream_t stream) {
+                                const float* ln_b, float* scratch, float* gain, int B, lh_stream_t stream) {
     using namespace lh;
-    if (!emb || !w || !bias || !ln_w || !ln_b || !gain || B <= 0) return LH_ERR_ARG;
-    hipLaunchKernelGGL(k_embed_proj_ln, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, w, bias, ln_w, ln_b, gain);
+    if (!emb || !w || !bias || !ln_w || !ln_b || !scratch || !gain || B <= 0 || scratch == gain) return LH_ERR_ARG;
+    hipLaunchKernelGGL(k_embed_proj, dim3((C * NF + EP_ROWS - 1) / EP_ROWS, (B + EP_NB - 1) / EP_NB), dim3(256), 0,
+                       (hipStream_t)stream, emb, w, bias, scratch, B);
+    hipLaunchKernelGGL(k_embed_ln, dim3(B), dim3(256), 0, (hipStream_t)stream, scratch, ln_w, ln_b, gain);
     return check_launch();
 }
 
-extern "C" int lh_abi_version(void) { return 1; }
+extern "C" int lh_abi_version(void) { return 2; }
 
 extern "C" int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unused, int lstm_hidden,
                                int n_heads, int attn_window, int n_srcs, int spk_emb_dim) {

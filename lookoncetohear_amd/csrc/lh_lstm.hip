@@ -185,6 +185,221 @@ __global__ void __launch_bounds__(256) k_ln_lstm(const float* __restrict__ x, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Split-precision variant ("f16x3"): every fp32 operand v is carried as two fp16 numbers
+//     hi = fp16(v),  lo = fp16((v - hi) * 2^11)                     (v - hi is exact in fp32)
+// and a product a*b is evaluated as  hi_a*hi_b + 2^-11 * (hi_a*lo_b + lo_a*hi_b)  on v_mfma_f32_16x16x32_f16
+// (fp16 products are exact in the fp32 accumulator; the dropped lo*lo term is 2^-22 relative).  That keeps
+// ~22 mantissa bits — the measured end-to-end error stays at the 1e-5 level against the 1e-3 budget — while
+// the three fp16 MFMAs (K=32 each) cost ~1/5 of the fp32 MFMA (K=4) they replace.  Same persistent structure:
+// weights resident in VGPRs (now as hi/lo fp16 fragments, same 128 registers), A = [LN(x_t) | h_{t-1}] staged
+// in LDS as fp16 hi/lo rows, one barrier per step.
+// ------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int LH_AP = 144;      // fp16 elements per LDS row: 128 + 16 pad (288 B: conflict-free ds_read_b128)
+constexpr int LH_HP = 68;       // fp32 copy of h: 64 + 4 pad
+constexpr float SPLIT_SCALE = 2048.0f;
+
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * SPLIT_SCALE);
+}
+
+template <int MT>
+__global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const float* __restrict__ x, const float* __restrict__ lnw,
+                                                    const float* __restrict__ lnb, const _Float16* __restrict__ w_pk,
+                                                    const float* __restrict__ b_sum, const float* __restrict__ h0,
+                                                    const float* __restrict__ c0, float* __restrict__ hN,
+                                                    float* __restrict__ cN, float* __restrict__ h_out, int nseq,
+                                                    int nstep, int sdiv, int so, int si, int ps, int ldh) {
+    constexpr int NS = 16 * MT;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
+    __shared__ __attribute__((aligned(16))) float hf[2 * NS * LH_HP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y;
+    const int s0 = blockIdx.x * NS;
+    const int g4 = lane >> 4, l15 = lane & 15;
+
+    auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
+    auto step_pos = [&](int it) -> int { return dir ? (nstep - 1 - it) : it; };
+
+    // resident weights: hi/lo fp16 B fragments, [gate][kstep]; image = [dir][wave][gate][ks][lane][hi8|lo8]
+    f16x8 wh[4][4], wl[4][4];
+    {
+        const _Float16* wp = w_pk + ((long)(dir * 4 + wave) * 16 * 64 + lane) * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wh[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16);
+                wl[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16 + 8);
+            }
+    }
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + wave * 16 + l15];
+
+    const int q = tid & 15;
+    const float4 gw = *reinterpret_cast<const float4*>(&lnw[q * 4]);
+    const float4 gb = *reinterpret_cast<const float4*>(&lnb[q * 4]);
+
+    auto load_x = [&](int it, float4 (&xr)[MT]) {
+        const int p = step_pos(it);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            const int s = min(s0 + rl, nseq - 1);
+            xr[i] = *reinterpret_cast<const float4*>(&x[row_of(s, p) * C + q * 4]);
+        }
+    };
+    auto store_split4 = [&](int buf, int rl, int col, float a, float b, float c, float d) {
+        f16x4 h4, l4;
+        _Float16 th, tl;
+        split_f16(a, th, tl); h4[0] = th; l4[0] = tl;
+        split_f16(b, th, tl); h4[1] = th; l4[1] = tl;
+        split_f16(c, th, tl); h4[2] = th; l4[2] = tl;
+        split_f16(d, th, tl); h4[3] = th; l4[3] = tl;
+        *reinterpret_cast<f16x4*>(&ahi[(buf * NS + rl) * LH_AP + col]) = h4;
+        *reinterpret_cast<f16x4*>(&alo[(buf * NS + rl) * LH_AP + col]) = l4;
+    };
+    auto norm_store_x = [&](int buf, float4 (&xr)[MT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            float4 v = xr[i];
+            const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+            v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+            const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+            const float rstd = rsqrtf(var + LN_EPS);
+            store_split4(buf, rl, q * 4, v.x * rstd * gw.x + gb.x, v.y * rstd * gw.y + gb.y, v.z * rstd * gw.z + gb.z,
+                         v.w * rstd * gw.w + gb.w);
+        }
+    };
+    auto flush_h = [&](int buf, int it) {
+        const int p = step_pos(it);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            const int s = s0 + rl;
+            if (s < nseq)
+                *reinterpret_cast<float4*>(&h_out[row_of(s, p) * ldh + dir * H + q * 4]) =
+                    *reinterpret_cast<const float4*>(&hf[(buf * NS + rl) * LH_HP + q * 4]);
+        }
+    };
+
+    float creg[MT][4];
+    {
+        float4 xr[MT];
+        load_x(0, xr);
+        norm_store_x(0, xr);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            const int s = min(s0 + rl, nseq - 1);
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
+            store_split4(0, rl, C + q * 4, hv.x, hv.y, hv.z, hv.w);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = min(s0 + m * 16 + g4 * 4 + r, nseq - 1);
+                creg[m][r] = c0 ? c0[(long)s * H + wave * 16 + l15] : 0.0f;
+            }
+    }
+    __syncthreads();
+
+    for (int it = 0; it < nstep; ++it) {
+        const int cur = it & 1, nxt = cur ^ 1;
+        float4 xr[MT];
+        const bool more = (it + 1 < nstep);
+        if (more) load_x(it + 1, xr);
+        if (it > 0) flush_h(cur, it - 1);
+
+        f32x4 accm[MT][4], accc[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                accm[m][g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
+                accc[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int ro = (cur * NS + m * 16 + l15) * LH_AP + g4 * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) accm[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], accm[m][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) accc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], accc[m][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) accc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], accc[m][g], 0, 0, 0);
+            }
+        }
+
+        const int unit = wave * 16 + l15;
+        constexpr float INV = 1.0f / SPLIT_SCALE;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = sigmoid_f(accm[m][0][r] + accc[m][0][r] * INV);
+                const float fg = sigmoid_f(accm[m][1][r] + accc[m][1][r] * INV);
+                const float gg = tanh_f(accm[m][2][r] + accc[m][2][r] * INV);
+                const float og = sigmoid_f(accm[m][3][r] + accc[m][3][r] * INV);
+                const float cc = fg * creg[m][r] + ig * gg;
+                creg[m][r] = cc;
+                const float hv = og * tanh_f(cc);
+                const int rl = m * 16 + g4 * 4 + r;
+                _Float16 th, tl;
+                split_f16(hv, th, tl);
+                ahi[(nxt * NS + rl) * LH_AP + C + unit] = th;
+                alo[(nxt * NS + rl) * LH_AP + C + unit] = tl;
+                hf[(nxt * NS + rl) * LH_HP + unit] = hv;
+            }
+        if (more) norm_store_x(nxt, xr);
+        __syncthreads();
+    }
+
+    const int last = nstep & 1;
+    flush_h(last, nstep - 1);
+    if (hN) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            const int s = s0 + rl;
+            if (s < nseq)
+                *reinterpret_cast<float4*>(&hN[(long)s * H + q * 4]) =
+                    *reinterpret_cast<const float4*>(&hf[(last * NS + rl) * LH_HP + q * 4]);
+        }
+    }
+    if (cN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = s0 + m * 16 + g4 * 4 + r;
+                if (s < nseq) cN[(long)s * H + wave * 16 + l15] = creg[m][r];
+            }
+    }
+}
+
+template <int MT>
+static int launch_lstm_h3(const float* x, const float* lnw, const float* lnb, const void* w_pk, const float* b_sum,
+                          const float* h0, const float* c0, float* hN, float* cN, float* h_out, int nseq, int nstep,
+                          int ndir, int sdiv, int so, int si, int ps, int ldh, hipStream_t st) {
+    constexpr int NS = 16 * MT;
+    hipLaunchKernelGGL((k_ln_lstm_h3<MT>), dim3((nseq + NS - 1) / NS, ndir), dim3(256), 0, st, x, lnw, lnb,
+                       (const _Float16*)w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, nstep, sdiv, so, si, ps, ldh);
+    return check_launch();
+}
+
 template <int MT>
 static int launch_lstm(const float* x, const float* lnw, const float* lnb, const float* w_pk, const float* b_sum,
                        const float* h0, const float* c0, float* hN, float* cN, float* h_out, int nseq, int nstep,
@@ -197,30 +412,59 @@ static int launch_lstm(const float* x, const float* lnw, const float* lnb, const
 
 }  // namespace lh
 
-extern "C" int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* ln_b, const float* w_pk,
-                                const float* b_sum, float* h_out, int n_frames, lh_stream_t stream) {
+namespace lh {
+static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto)
+}
+extern "C" int lh_set_tuning(int key, int value) {
+    if (key < 0 || key >= 4) return LH_ERR_ARG;
+    lh::g_tune[key] = value;
+    return LH_OK;
+}
+
+extern "C" int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* ln_b, const void* w_pk,
+                                const float* b_sum, float* h_out, int n_frames, int mode, lh_stream_t stream) {
     using namespace lh;
     if (!x || !ln_w || !ln_b || !w_pk || !b_sum || !h_out || n_frames <= 0) return LH_ERR_ARG;
     // sequence s = frame (b,t); step p = frequency bin; row(s,p) = s*97 + p
-    if (n_frames >= 8192)
-        return launch_lstm<2>(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1,
+    const int mt = g_tune[0] ? g_tune[0] : (mode == LH_GEMM_F16X3 ? 1 : (n_frames >= 8192 ? 2 : 1));
+    if (mode == LH_GEMM_F16X3) {
+        if (mt == 2)
+            return launch_lstm_h3<2>(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF,
+                                     2, 1, NF, 0, 1, 2 * H, (hipStream_t)stream);
+        return launch_lstm_h3<1>(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2,
+                                 1, NF, 0, 1, 2 * H, (hipStream_t)stream);
+    }
+    if (mode != LH_GEMM_F32) return LH_ERR_UNSUPPORTED;
+    const float* w_f32 = (const float*)w_pk;
+    if (mt == 2)
+        return launch_lstm<2>(x, ln_w, ln_b, w_f32, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1,
                               NF, 0, 1, 2 * H, (hipStream_t)stream);
-    return launch_lstm<1>(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1, NF,
+    return launch_lstm<1>(x, ln_w, ln_b, w_f32, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1, NF,
                           0, 1, 2 * H, (hipStream_t)stream);
 }
 
-extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const float* w_pk,
+extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const void* w_pk,
                                 const float* b_sum, const float* h0, const float* c0, float* hN, float* cN,
-                                float* h_out, int B, int T, lh_stream_t stream) {
+                                float* h_out, int B, int T, int mode, lh_stream_t stream) {
     using namespace lh;
     if (!x || !ln_w || !ln_b || !w_pk || !b_sum || !h0 || !c0 || !hN || !cN || !h_out || B <= 0 || T <= 0)
         return LH_ERR_ARG;
     if (h0 == hN || c0 == cN) return LH_ERR_ARG;
     // sequence s = b*97 + f; step p = frame t; row(s,p) = (b*T + p)*97 + f
     const int nseq = B * NF;
-    if (nseq >= 32768)
-        return launch_lstm<2>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
+    const int mt = g_tune[1] ? g_tune[1] : (nseq >= 32768 ? 2 : 1);
+    if (mode == LH_GEMM_F16X3) {
+        if (mt == 2)
+            return launch_lstm_h3<2>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
+                                     (hipStream_t)stream);
+        return launch_lstm_h3<1>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
+                                 (hipStream_t)stream);
+    }
+    if (mode != LH_GEMM_F32) return LH_ERR_UNSUPPORTED;
+    const float* w_f32 = (const float*)w_pk;
+    if (mt == 2)
+        return launch_lstm<2>(x, ln_w, ln_b, w_f32, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
                               (hipStream_t)stream);
-    return launch_lstm<1>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
+    return launch_lstm<1>(x, ln_w, ln_b, w_f32, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
                           (hipStream_t)stream);
 }

@@ -108,24 +108,25 @@ __global__ void __launch_bounds__(256) k_qkv_proj_ln(const float* __restrict__ y
                                                      const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
                                                      const float* __restrict__ lnv_w, const float* __restrict__ lnv_b,
                                                      float* __restrict__ q, float* __restrict__ kx,
-                                                     float* __restrict__ vx, int T) {
+                                                     float* __restrict__ vx, int T, int nframes) {
     constexpr int NT = NQKV / 16;         // 7 N tiles
     constexpr int YP = NQKV + 1;          // 113: odd stride -> conflict-free column walks in the LN phase
     __shared__ __attribute__((aligned(16))) float as[4 * FR_MT * 16 * FR_KP];
     __shared__ float ys[NF * YP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
-    const int t = blockIdx.x, b = blockIdx.y;
 
-    float wreg[NT][16];
+    float wreg[NT][16];                   // weights loaded once per persistent workgroup
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) wreg[nt][ks] = w_pk[(nt * 16 + ks) * 64 + lane];
-
-    stage_frame(y + ((long)b * T + t) * NF * C, as, tid);
-    __syncthreads();
-
     const float sq = slopes[0], sk = slopes[1], sv = slopes[2];
+
+  for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
+    const int b = fr / T, t = fr % T;
+    stage_frame(y + (long)fr * NF * C, as, tid);
+    __syncthreads();                      // also orders the previous frame's LDS reads of `ys`
+
     for (int m = wave; m < FR_MT; m += 4) {
         f32x4 acc[NT];
 #pragma unroll
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(256) k_qkv_proj_ln(const float* __restrict__ y
             dst[i] = o;
         }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -193,25 +195,26 @@ __global__ void __launch_bounds__(256) k_proj_ln_res(const float* __restrict__ m
                                                      const float* __restrict__ bias, const float* __restrict__ slope,
                                                      const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                      const float* __restrict__ y2, const float* __restrict__ gain,
-                                                     float* __restrict__ out, int T) {
+                                                     float* __restrict__ out, int T, int nframes) {
     constexpr int YP = C + 4;
     __shared__ __attribute__((aligned(16))) float as[4 * FR_MT * 16 * FR_KP];
     __shared__ __attribute__((aligned(16))) float ys[NF * YP];
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
-    const int t = blockIdx.x, b = blockIdx.y;
-    const long fr = ((long)b * T + t) * NF * C;
 
-    float wreg[4][16];
+    float wreg[4][16];                    // weights loaded once per persistent workgroup
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) wreg[nt][ks] = w_pk[(nt * 16 + ks) * 64 + lane];
-
-    stage_frame(merged + fr, as, tid);
-    __syncthreads();
-
     const float a = slope[0];
+
+  for (int fidx = blockIdx.x; fidx < nframes; fidx += gridDim.x) {     // grid-stride over frames (b*T + t)
+    const int b = fidx / T;
+    const long fr = (long)fidx * NF * C;
+    stage_frame(merged + fr, as, tid);
+    __syncthreads();                      // also orders the previous frame's LDS reads of `ys`
+
     for (int m = wave; m < FR_MT; m += 4) {
         f32x4 acc[4];
 #pragma unroll
@@ -271,6 +274,7 @@ __global__ void __launch_bounds__(256) k_proj_ln_res(const float* __restrict__ m
         }
         *reinterpret_cast<float4*>(&out[fr + i * 4]) = o;
     }
+  }
 }
 
 }  // namespace lh
@@ -298,8 +302,9 @@ extern "C" int lh_qkv_proj_ln(const float* y, const float* w_pk, const float* bi
     if (!y || !w_pk || !bias || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !q || !kx ||
         !vx || B <= 0 || T <= 0)
         return LH_ERR_ARG;
-    hipLaunchKernelGGL(k_qkv_proj_ln, dim3(T, B), dim3(256), 0, (hipStream_t)stream, y, w_pk, bias, slopes, lnq_w,
-                       lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, q, kx, vx, T);
+    const int nframes = B * T;
+    hipLaunchKernelGGL(k_qkv_proj_ln, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y, w_pk,
+                       bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, q, kx, vx, T, nframes);
     return check_launch();
 }
 
@@ -308,7 +313,8 @@ extern "C" int lh_proj_ln_res(const float* merged, const float* w_pk, const floa
                               int B, int T, lh_stream_t stream) {
     using namespace lh;
     if (!merged || !w_pk || !bias || !slope || !ln_w || !ln_b || !y2 || !out || B <= 0 || T <= 0) return LH_ERR_ARG;
-    hipLaunchKernelGGL(k_proj_ln_res, dim3(T, B), dim3(256), 0, (hipStream_t)stream, merged, w_pk, bias, slope, ln_w,
-                       ln_b, y2, gain, out, T);
+    const int nframes = B * T;
+    hipLaunchKernelGGL(k_proj_ln_res, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, merged,
+                       w_pk, bias, slope, ln_w, ln_b, y2, gain, out, T, nframes);
     return check_launch();
 }

@@ -22,6 +22,7 @@ path raises if the HIP library is missing or the tensors are not on the GPU).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -142,6 +143,9 @@ class Net(nn.Module):
         self.E = math.ceil(512 * 1.0 / self.n_freqs)
         self.V_dim = D // L
         self.tfgridnet = _TFGridNetParams(self.nfft, stft_chunk_size, num_ch, num_src, D, B, H, L, embed_dim)
+        # contraction arithmetic of the recurrent kernels: "f16x3" = split-precision fp16 MFMA (hi/lo operands,
+        # ~22 mantissa bits, ~5x the fp32-MFMA rate), "f32" = exact fp32 MFMA.  LOOKONCE_GEMM overrides.
+        self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
         self._pack_key = None
         self._packed = None
         self._ws: Dict[tuple, dict] = {}
@@ -218,7 +222,7 @@ class Net(nn.Module):
             hist = self.local_atten_len - 1
             ws = dict(xa=e(B, T, F_, C_), xb=e(B, T, F_, C_), xc=e(B, T, F_, C_), hbuf=e(B * T * F_, 2 * self.hidden),
                       q=e(B * nh, T, 584), kx=torch.zeros(B * nh, T + hist, 584, device=device),
-                      vx=e(B * nh, T + hist, self.V_dim * F_), gain=e(B, F_, C_))
+                      vx=e(B * nh, T + hist, self.V_dim * F_), gain=e(B, F_, C_), gain_raw=e(B, F_ * C_))
             self._ws[key] = ws
         return ws
 
@@ -267,24 +271,28 @@ class Net(nn.Module):
             lib.call("lh_stft_conv_in", P(x), P(conv_in), P(conv_out), P(pk["wfb_t"]), P(pk["conv_w"]),
                      P(pk["conv_b"]), P(xa), Bn, T, ns, st)
             lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]),
-                     P(pk["emb_ln_b"]), P(ws["gain"]), Bn, st)
+                     P(pk["emb_ln_b"]), P(ws["gain_raw"]), P(ws["gain"]), Bn, st)
             if taps is not None:
                 taps["Z0"], taps["G"] = xa.clone(), ws["gain"].clone()
 
             rows = Bn * T * F_
+            if self.gemm_mode not in ("f32", "f16x3"):
+                raise ValueError(f"gemm_mode must be 'f32' or 'f16x3', got {self.gemm_mode!r}")
+            mode = 1 if self.gemm_mode == "f16x3" else 0
+            wkey = "_w16" if mode else "_w"
             for i in range(self.n_blocks):
                 bp = pk["blocks"][i]
                 bs = state["gridnet_bufs"][f"buf{i}"]
                 # intra: LN + BiLSTM over frequency -> Linear(128->64) + residual
-                lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra_w"]),
-                         P(bp["intra_b"]), P(hbuf), Bn * T, st)
+                lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra" + wkey]),
+                         P(bp["intra_b"]), P(hbuf), Bn * T, mode, st)
                 lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
                          2 * H_, st)
                 # inter: LN + causal LSTM over time with carried state -> Linear(64->64) + residual
                 h0, c0 = c32(bs["h0"]), c32(bs["c0"])
                 hN, cN = new(h0), new(c0)
-                lib.call("lh_ln_lstm_inter", P(xb), P(bp["inter_ln_w"]), P(bp["inter_ln_b"]), P(bp["inter_w"]),
-                         P(bp["inter_b"]), P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, st)
+                lib.call("lh_ln_lstm_inter", P(xb), P(bp["inter_ln_w"]), P(bp["inter_ln_b"]), P(bp["inter" + wkey]),
+                         P(bp["inter_b"]), P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, mode, st)
                 lib.call("lh_linear_res", P(hbuf), P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(xb), P(xc), rows,
                          H_, st)
                 # attention: history rows in, Q/K/V, local attention (head merge fused), projection + LN + residual

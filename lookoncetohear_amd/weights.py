@@ -39,12 +39,47 @@ def pack_lstm(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
     return wcat[col, k].contiguous().float()
 
 
+SPLIT_SCALE = 2048.0      # 2^11: fp16 has 11 significant bits; lo = fp16((v - fp16(v)) * 2^11)
+
+
+def split_f16(v: torch.Tensor):
+    """fp32 -> (hi, lo) fp16 pair with v ~= hi + lo / 2^11 (about 22 significant bits)."""
+    hi = v.float().half()
+    lo = ((v.float() - hi.float()) * SPLIT_SCALE).half()
+    return hi, lo
+
+
+def pack_lstm_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """Split-precision image for v_mfma_f32_16x16x32_f16: [4 waves, 4 gates, 4 ksteps, 64 lanes, 2 (hi|lo), 8] fp16.
+
+    Lane l of (wave w, gate g, k-step ks) holds column g*H + 16w + (l & 15) of [W_ih | W_hh] at
+    k = ks*32 + (l >> 4)*8 + j, j = 0..7 (x channels 0..63, then hidden units 0..63)."""
+    H = w_hh.shape[1]
+    assert H == 64 and tuple(w_ih.shape) == (4 * H, 64)
+    wcat = torch.cat([w_ih, w_hh], dim=1).float()               # [256, 128]
+    dev = wcat.device
+    lane = torch.arange(64, device=dev)
+    wave = torch.arange(4, device=dev)[:, None, None, None, None]
+    gate = torch.arange(4, device=dev)[None, :, None, None, None]
+    ks = torch.arange(4, device=dev)[None, None, :, None, None]
+    j = torch.arange(8, device=dev)[None, None, None, None, :]
+    col = gate * H + wave * 16 + (lane & 15)[None, None, None, :, None]
+    k = ks * 32 + (lane >> 4)[None, None, None, :, None] * 8 + j
+    frag = wcat[col, k]                                          # [4,4,4,64,8]
+    hi, lo = split_f16(frag)
+    return torch.stack([hi, lo], dim=4).contiguous()             # [4,4,4,64,2,8]
+
+
 def pack_block(sd: dict, pre: str) -> dict:
     g = lambda k: sd[pre + k].detach()
     out = {}
     out["intra_ln_w"], out["intra_ln_b"] = g("intra_norm.norm.weight"), g("intra_norm.norm.bias")
     out["intra_w"] = torch.stack([pack_lstm(g("intra_rnn.weight_ih_l0"), g("intra_rnn.weight_hh_l0")),
                                   pack_lstm(g("intra_rnn.weight_ih_l0_reverse"), g("intra_rnn.weight_hh_l0_reverse"))])
+    out["intra_w16"] = torch.stack([pack_lstm_f16x3(g("intra_rnn.weight_ih_l0"), g("intra_rnn.weight_hh_l0")),
+                                    pack_lstm_f16x3(g("intra_rnn.weight_ih_l0_reverse"),
+                                                    g("intra_rnn.weight_hh_l0_reverse"))])
+    out["inter_w16"] = pack_lstm_f16x3(g("inter_rnn.weight_ih_l0"), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
     out["intra_lin_w"], out["intra_lin_b"] = pack_linear(g("intra_linear.weight")), g("intra_linear.bias")
@@ -62,7 +97,7 @@ def pack_block(sd: dict, pre: str) -> dict:
     out["proj_w"], out["proj_b"] = pack_linear(g("attn_concat_proj.0.weight")), g("attn_concat_proj.0.bias")
     out["proj_slope"] = g("attn_concat_proj.1.weight")
     out["proj_ln_w"], out["proj_ln_b"] = g("attn_concat_proj.3.norm.weight"), g("attn_concat_proj.3.norm.bias")
-    return {k: v.contiguous().float() for k, v in out.items()}
+    return {k: (v.contiguous() if v.dtype == torch.float16 else v.contiguous().float()) for k, v in out.items()}
 
 
 def pack_all(sd: dict, n_blocks: int, prefix: str = "tfgridnet.") -> dict:

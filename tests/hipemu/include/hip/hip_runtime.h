@@ -77,6 +77,7 @@ struct WaveState {
     unsigned arrived = 0, gen = 0, alive = 0;
     float sa[64], sb[64];
     uint64_t su[64];
+    _Float16 ha[64][8], hb[64][8];
 };
 
 struct BlockState {
@@ -238,6 +239,26 @@ inline v16f mfma_32x32x2(float a, float b, v16f c) {
     return c;
 }
 
+// v_mfma_f32_16x16x32_f16: lane l holds A[i=l&15][k=(l>>4)*8+j], B[k=(l>>4)*8+j][n=l&15], j=0..7;
+// D as the f32 16x16 forms.  Products are exact in f32; accumulation order (k ascending) is an emulator choice.
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+inline v4f mfma_16x16x32_f16(v8h a, v8h b, v4f c) {
+    WaveState& w = my_wave();
+    int l = lane_id();
+    for (int j = 0; j < 8; ++j) { w.ha[l][j] = a[j]; w.hb[l][j] = b[j]; }
+    wave_barrier();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float s = c[r];
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 8; ++j) s += (float)w.ha[g * 16 + row][j] * (float)w.hb[g * 16 + col][j];
+        c[r] = s;
+    }
+    wave_barrier();
+    return c;
+}
+
 }  // namespace hipemu
 
 // x86-64 SysV context switch: save callee-saved registers, swap stack pointers.
@@ -295,6 +316,7 @@ template <class T> static inline T __shfl_up(T v, int d, int width = 64) {
 
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu::mfma_16x16x32_f16((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
