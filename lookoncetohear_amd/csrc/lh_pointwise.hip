@@ -99,10 +99,29 @@ __device__ __forceinline__ void stage_frame(const float* __restrict__ src, float
     }
 }
 
+// One wave: LayerNorm over the NF*D values ys[f][col0 + e] (flat index f*D + e), affine per flat index, written
+// to dst[0..ld) (columns >= NF*D are zero padding).  D is compile-time so the index split is shifts / mul-shift.
+template <int D>
+__device__ __forceinline__ void ln_head(const float* ys, int yp, int col0, const float* __restrict__ gw,
+                                        const float* __restrict__ gb, float* __restrict__ dst, int ld, int lane) {
+    constexpr int N = NF * D;
+    float s = 0.f;
+    for (int i = lane; i < N; i += 64) s += ys[(i / D) * yp + col0 + (i % D)];
+    const float mean = wave_sum(s) * (1.0f / N);
+    float v = 0.f;
+    for (int i = lane; i < N; i += 64) { const float dv = ys[(i / D) * yp + col0 + (i % D)] - mean; v += dv * dv; }
+    const float rstd = rsqrtf(wave_sum(v) * (1.0f / N) + LN_EPS);
+    for (int i = lane; i < ld; i += 64) {
+        float o = 0.f;
+        if (i < N) o = (ys[(i / D) * yp + col0 + (i % D)] - mean) * rstd * gw[i] + gb[i];
+        dst[i] = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
-// Q/K/V projection + PReLU + per-head LayerNorm over (f,e);  grid (T, B), one frame per workgroup
+// Q/K/V projection + PReLU + per-head LayerNorm over (f,e); persistent workgroups, grid-stride over frames
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_qkv_proj_ln(const float* __restrict__ y, const float* __restrict__ w_pk,
+__global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict__ y, const float* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slopes,
                                                      const float* __restrict__ lnq_w, const float* __restrict__ lnq_b,
                                                      const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
@@ -158,40 +177,19 @@ __global__ void __launch_bounds__(256) k_qkv_proj_ln(const float* __restrict__ y
     }
     __syncthreads();
 
-    // per-head LayerNorm: wave w normalises head w of Q, K and V; flat index = f*d + e (F-major, e-minor)
+    // per-head LayerNorm: wave w normalises head w of Q, K and V; flat index = f*D + e (F-major, e-minor)
     const int hd = wave;
     const long bh = (long)b * NH + hd;
-#pragma unroll 1
-    for (int which = 0; which < 3; ++which) {
-        const int d = which == 2 ? VD : E;
-        const int n = NF * d;
-        const int col0 = which == 0 ? hd * E : (which == 1 ? NH * E + hd * E : 2 * NH * E + hd * VD);
-        const float* gw = which == 0 ? lnq_w : (which == 1 ? lnk_w : lnv_w);
-        const float* gb = which == 0 ? lnq_b : (which == 1 ? lnk_b : lnv_b);
-        float s = 0.f;
-        for (int i = lane; i < n; i += 64) s += ys[(i / d) * YP + col0 + (i % d)];
-        const float mean = wave_sum(s) / n;
-        float v = 0.f;
-        for (int i = lane; i < n; i += 64) { const float dv = ys[(i / d) * YP + col0 + (i % d)] - mean; v += dv * dv; }
-        const float rstd = rsqrtf(wave_sum(v) / n + LN_EPS);
-        float* dst;
-        int ld;
-        if (which == 0) { dst = q + (bh * T + t) * LDQK; ld = LDQK; }
-        else if (which == 1) { dst = kx + (bh * (T + HIST) + HIST + t) * LDQK; ld = LDQK; }
-        else { dst = vx + (bh * (T + HIST) + HIST + t) * DV; ld = DV; }
-        for (int i = lane; i < ld; i += 64) {
-            float o = 0.f;                                   // q/kx pad columns 582,583 are kept at zero
-            if (i < n) o = (ys[(i / d) * YP + col0 + (i % d)] - mean) * rstd * gw[i] + gb[i];
-            dst[i] = o;
-        }
-    }
+    ln_head<E>(ys, YP, hd * E, lnq_w, lnq_b, q + (bh * T + t) * LDQK, LDQK, lane);
+    ln_head<E>(ys, YP, NH * E + hd * E, lnk_w, lnk_b, kx + (bh * (T + HIST) + HIST + t) * LDQK, LDQK, lane);
+    ln_head<VD>(ys, YP, 2 * NH * E + hd * VD, lnv_w, lnv_b, vx + (bh * (T + HIST) + HIST + t) * DV, DV, lane);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // attn_concat_proj + LN over (f,c) + residual (+ speaker gain);  grid (T, B), one frame per workgroup
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_proj_ln_res(const float* __restrict__ merged, const float* __restrict__ w_pk,
+__global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict__ merged, const float* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slope,
                                                      const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                      const float* __restrict__ y2, const float* __restrict__ gain,
@@ -208,6 +206,15 @@ __global__ void __launch_bounds__(256) k_proj_ln_res(const float* __restrict__ m
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) wreg[nt][ks] = w_pk[(nt * 16 + ks) * 64 + lane];
     const float a = slope[0];
+    // LayerNorm affine of this thread's fixed float4 slots, resident for all frames of the persistent loop
+    constexpr int NSLOT = (NF * C / 4 + 255) / 256;      // 7
+    float4 pw[NSLOT], pb[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        const int i = min(tid + 256 * k, NF * C / 4 - 1);
+        pw[k] = *reinterpret_cast<const float4*>(&lnw[i * 4]);
+        pb[k] = *reinterpret_cast<const float4*>(&lnb[i * 4]);
+    }
 
   for (int fidx = blockIdx.x; fidx < nframes; fidx += gridDim.x) {     // grid-stride over frames (b*T + t)
     const int b = fidx / T;
@@ -258,10 +265,12 @@ __global__ void __launch_bounds__(256) k_proj_ln_res(const float* __restrict__ m
         vs += dx * dx + dy * dy + dz * dz + dw * dw;
     }
     const float rstd = rsqrtf(block_sum_256(vs, red) * (1.0f / N) + LN_EPS);
-    for (int i = tid; i < N4; i += 256) {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        const int i = tid + 256 * k;
+        if (i >= N4) break;
         const float4 v = *reinterpret_cast<const float4*>(&ys[(i >> 4) * YP + (i & 15) * 4]);
-        const float4 gw = *reinterpret_cast<const float4*>(&lnw[i * 4]);
-        const float4 gb = *reinterpret_cast<const float4*>(&lnb[i * 4]);
+        const float4 gw = pw[k], gb = pb[k];
         const float4 rv = *reinterpret_cast<const float4*>(&y2[fr + i * 4]);
         float4 o;
         o.x = rv.x + (v.x - mean) * rstd * gw.x + gb.x;

@@ -1,27 +1,49 @@
 """Dump a rocprofv3 (rocpd sqlite) result database to the small text summaries kept under profiles/.
 
-    python scripts/rocpd_summary.py gpurun_out/prof_stats/r1_results.db profiles/r01_kernel_stats.csv
+    python scripts/rocpd_summary.py <results.db> <out.csv>          # kernel stats (top_kernels view)
+    python scripts/rocpd_summary.py <results.db> <out.csv> --pmc    # per-kernel average of each collected counter
 """
 import csv
 import sqlite3
 import sys
 
 
-def main(db, out):
+def short(name):
+    return name.split("(")[0].replace("void ", "")[:100]
+
+
+def main(db, out, pmc=False):
     c = sqlite3.connect(db)
-    rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_us", "avg_us", "pct"])
-        for name, calls, tot, avg, pct in rows:
-            short = name.split("(")[0].replace("void ", "")
-            w.writerow([short[:120], calls, f"{tot:.1f}", f"{avg:.1f}", f"{pct:.2f}"])
-    try:
-        pm = c.execute("select k.name, p.pmc_name if 0 else '' from kernels k limit 0").fetchall()
-    except Exception:
-        pass
-    print("wrote", out, len(rows), "kernels")
+        if not pmc:
+            rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+            w.writerow(["kernel", "calls", "total_us", "avg_us", "pct"])
+            for name, calls, tot, avg, pct in rows:
+                w.writerow([short(name), calls, f"{tot / 1e3:.1f}" if tot > 1e6 else f"{tot:.1f}", f"{avg:.1f}", f"{pct:.2f}"])
+            print("wrote", out, len(rows), "kernels")
+            return
+        cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+        w.writerow(["# counters_collection columns: " + " ".join(cols)])
+        kcol = "kernel_name" if "kernel_name" in cols else ("name" if "name" in cols else None)
+        ccol = "counter_name" if "counter_name" in cols else None
+        vcol = "value" if "value" in cols else ("counter_value" if "counter_value" in cols else None)
+        if not (kcol and ccol and vcol):
+            print("unknown schema", cols)
+            return
+        did = "dispatch_id" if "dispatch_id" in cols else None
+        q = (f"select {kcol}, {ccol}, count(*), sum({vcol}) from counters_collection group by {kcol}, {ccol}")
+        if did:  # a counter may have several rows per dispatch (per XCC/instance): sum within a dispatch first
+            q = (f"select k, cn, count(*), avg(v) from (select {kcol} as k, {ccol} as cn, {did} as d, sum({vcol}) as v "
+                 f"from counters_collection group by {kcol}, {ccol}, {did}) group by k, cn")
+        w.writerow(["kernel", "counter", "dispatches", "avg_per_dispatch"])
+        n = 0
+        for k, cn, cnt, v in c.execute(q):
+            if "lh::" in k:
+                w.writerow([short(k), cn, cnt, f"{v:.6g}"])
+                n += 1
+        print("wrote", out, n, "rows")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], "--pmc" in sys.argv)

@@ -20,7 +20,7 @@ def build_emu(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-march=native",
            "-I", os.path.join(HERE, "include"), *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
