@@ -91,22 +91,24 @@ int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const
 
 /* Row-wise Linear(K->64) + bias + residual:  out[r][:] = res[r][:] + W h[r][:] + b.
  * Replaces intra_linear + residual (tfgridnet_causal.py:513-516, K=128) and inter_linear + view/transpose +
- * residual (:534-538, K=64).   h [rows][K]; w_pk [4 ntiles][K/4 ksteps][64 lanes]; bias [64]; res,out [rows][64]
+ * residual (:534-538, K=64).   h [rows][K]; bias [64]; res,out [rows][64];
+ *   w_pk  split-precision fp16 image [4 ntiles][K/32 ksteps][64 lanes][hi 8 | lo 8] (weights.py pack_linear_f16x3)
  */
-int lh_linear_res(const float* h, const float* w_pk, const float* bias, const float* res, float* out, int rows,
+int lh_linear_res(const float* h, const void* w_pk, const float* bias, const float* res, float* out, int rows,
                   int K, lh_stream_t stream);
 
 /* A.3.3  Q/K/V: pointwise Linear + PReLU, head split, joint LayerNorm over (f,e) per head.
  * Replaces attn_conv_Q/K/V (tfgridnet_causal.py:354-387, used :547-551) and the K/V history concat (:553-562):
  * K and V rows are written at row (hist + t) of the history-extended buffers.
  *   y      [B][T][97][64]
- *   w_pk   [7 ntiles][16 ksteps][64 lanes]  rows 0..23 Q(h*6+e), 24..47 K, 48..111 V(h*16+v); bias [112]
+ *   w_pk   fp16 hi/lo image [7 ntiles][2 ksteps][64 lanes][16] of the stacked weight, rows 0..23 Q(h*6+e),
+ *          24..47 K, 48..111 V(h*16+v); bias [112]
  *   slopes [3] PReLU slopes (Q,K,V);  lnq_w/b, lnk_w/b [582];  lnv_w/b [1552]
  *   q      [B*4][T][584]            (row stride 584 = 582 padded to 16 B; pad columns are written as 0)
  *   kx     [B*4][T+49][584]         rows 0..48 = history (filled by the caller from K_buf), row 49+t = K[t]
  *   vx     [B*4][T+49][1552]
  */
-int lh_qkv_proj_ln(const float* y, const float* w_pk, const float* bias, const float* slopes, const float* lnq_w,
+int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const float* slopes, const float* lnq_w,
                    const float* lnq_b, const float* lnk_w, const float* lnk_b, const float* lnv_w,
                    const float* lnv_b, float* q, float* kx, float* vx, int B, int T, lh_stream_t stream);
 
@@ -122,9 +124,9 @@ int lh_local_attn(const float* q, const float* kx, const float* vx, float* merge
 /* A.3.6  attn_concat_proj: Linear(64->64)+PReLU, joint LayerNorm over (f,c), residual; optional speaker gain.
  * Replaces tfgridnet_causal.py:583-588 and, when gain != NULL, the `batch = batch * embed` applied to the
  * input of block 1 (:250-251):  out = (y2 + LN(PReLU(W m + b))) * gain[b][f][c].
- *   merged, y2, out [B][T][97][64]; w_pk [4][16][64]; bias [64]; slope [1]; ln_w/b [6208]; gain [B][97][64]|NULL
+ *   merged, y2, out [B][T][97][64]; w_pk fp16 hi/lo image [4][2][64][16]; bias [64]; slope [1]; ln_w/b [6208]; gain [B][97][64]|NULL
  */
-int lh_proj_ln_res(const float* merged, const float* w_pk, const float* bias, const float* slope,
+int lh_proj_ln_res(const float* merged, const void* w_pk, const float* bias, const float* slope,
                    const float* ln_w, const float* ln_b, const float* y2, const float* gain, float* out, int B,
                    int T, lh_stream_t stream);
 

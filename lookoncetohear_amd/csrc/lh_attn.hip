@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(256) k_local_attn(const float* __restrict__ q,
         const float* krow[AT_NKT];
 #pragma unroll
         for (int nt = 0; nt < AT_NKT; ++nt) krow[nt] = kb + (long)min(t0 + nt * 16 + l15, TK - 1) * LDQK;
+#pragma unroll 2
         for (int it = 0; it < (AT_F4 + 15) / 16; ++it) {
             const int f4 = it * 16 + wave * 4 + g4;
             const bool ok = f4 < AT_F4;

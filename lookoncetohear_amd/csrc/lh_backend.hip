@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256) k_deconv_istft(const float* __restrict__ 
                     const float* w0 = &wd[((0 * 3 + kt) * 3 + kf) * C];
                     if (fr >= 0) {
                         const float* src = y + (((long)b * T + fr) * NF + fi) * C;
+#pragma unroll
                         for (int c4 = 0; c4 < C / 4; ++c4) {
                             const float4 v = *reinterpret_cast<const float4*>(src + c4 * 4);
 #pragma unroll
@@ -89,6 +90,7 @@ __global__ void __launch_bounds__(256) k_deconv_istft(const float* __restrict__ 
         for (int j = 0; j < BE_NJ; ++j)
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) acc[j][s] = 0.f;
+#pragma unroll 8
         for (int k = 0; k < NK; ++k) {
             const float w = wfb[k * NFFT + tid];
 #pragma unroll

@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256) k_stft_conv_in(const float* __restrict__ 
         for (int m = 0; m < NMIC; ++m)
 #pragma unroll
             for (int j = 0; j < FE_NJ; ++j) acc[m][j] = 0.0f;
+#pragma unroll 8
         for (int n = 0; n < NFFT; ++n) {
             const float w = wfb_t[n * NK + k];
 #pragma unroll
@@ -168,7 +169,7 @@ extern "C" int lh_embed_proj_ln(const float* emb, const float* w, const float* b
     return check_launch();
 }
 
-extern "C" int lh_abi_version(void) { return 2; }
+extern "C" int lh_abi_version(void) { return 3; }
 
 extern "C" int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unused, int lstm_hidden,
                                int n_heads, int attn_window, int n_srcs, int spk_emb_dim) {

@@ -1,101 +1,168 @@
-// Pointwise (per time-frequency unit) channel contractions on fp32 MFMA with fused epilogues:
-//   k_linear_res   out = res + W h + b                       (intra_linear / inter_linear + residual)
-//   k_qkv_proj_ln  Q/K/V = LN_(f,e)(PReLU(W y + b)) per head  (attn_conv_Q/K/V)
-//   k_proj_ln_res  out = (y2 + LN_(f,c)(PReLU(W m + b))) * gain   (attn_concat_proj + residual + speaker gain)
-// All three stage a [rows x K] activation tile in LDS (coalesced 256-byte rows), keep the weight matrix in
-// VGPRs as v_mfma_f32_16x16x4_f32 B fragments, and run their LayerNorm/activation epilogue out of LDS so
-// every activation byte crosses HBM once per stage (SURVEY.md §8d "algorithmic bytes").
+// Pointwise (per time-frequency unit) channel contractions with fused epilogues:
+//   k_linear_res   out = res + W h + b                            (intra_linear / inter_linear + residual)
+//   k_qkv_proj_ln  Q/K/V = LN_(f,e)(PReLU(W y + b)) per head       (attn_conv_Q/K/V)
+//   k_proj_ln_res  out = (y2 + LN_(f,c)(PReLU(W m + b))) * gain    (attn_concat_proj + residual + speaker gain)
+//
+// These are HBM-streaming stages: every activation byte should cross HBM once per stage, so
+//   * workgroups are persistent (grid-stride over row tiles / frames) and keep their weights in VGPRs;
+//   * global loads of a tile are all issued before the first dependent LDS write (register staging; hipcc does
+//     not unroll a load->ds_write loop by itself and otherwise serialises one HBM round trip per float4), and the
+//     next frame is prefetched into registers while the current one is processed;
+//   * the contraction runs on split-precision fp16 MFMA ("f16x3": v = hi + 2^-11 lo, products hi*hi + 2^-11
+//     (hi*lo + lo*hi) on v_mfma_f32_16x16x32_f16, ~22 mantissa bits, see lh_lstm.hip) so the matrix pipe costs
+//     ~1/5 of fp32 MFMA and stays hidden behind the memory stream;
+//   * each WAVE owns output-column tiles (not row tiles): its weight fragments are 16-32 registers instead of
+//     112-128, which keeps 2-3 workgroups resident per CU for latency hiding;
+//   * LayerNorm / PReLU / residual epilogues run out of LDS with compile-time index algebra.
 #include "lh_common.h"
 
 namespace lh {
 
-// ------------------------------------------------------------------------------------------------------
-// out[r][0:64] = res[r][0:64] + bias + sum_k h[r][k] * W[o][k]       K in {64, 128}
-// persistent grid-stride over 64-row tiles; weights loaded once per workgroup.
-// ------------------------------------------------------------------------------------------------------
-template <int K>
-__global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h, const float* __restrict__ w_pk,
-                                                    const float* __restrict__ bias, const float* __restrict__ res,
-                                                    float* __restrict__ out, int rows) {
-    constexpr int KC = K / 4;            // floats per k-chunk (one chunk per 16-lane group)
-    constexpr int KP = KC + 4;           // padded LDS row
-    constexpr int CP = C + 4;
-    __shared__ __attribute__((aligned(16))) float as[4 * 64 * KP];
-    __shared__ __attribute__((aligned(16))) float cs[4 * 16 * CP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr float PW_SPLIT = 2048.0f;
 
-    float wreg[4][KC];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < KC; ++ks) wreg[nt][ks] = w_pk[(nt * KC + ks) * 64 + lane];
-    float bz[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bz[nt] = bias[nt * 16 + l15];
+// A-operand LDS image for v_mfma_f32_16x16x32_f16: [kstep][16-lane group][row][8 halves]; a lane's 16 bytes of
+// consecutive rows are consecutive 16-byte slots -> conflict-free ds_read_b128, no padding.
+template <int RP>
+__device__ __forceinline__ int a_index(int row, int k) {
+    return (((k >> 5) * 4 + ((k >> 3) & 3)) * RP + row) * 8 + (k & 7);
+}
 
-    const int ntiles = (rows + 63) / 64;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long r0 = (long)tile * 64;
-        // stage 64 rows x K floats (float4 granules, a row is contiguous)
-        for (int e = tid; e < 64 * (K / 4); e += 256) {
-            const int rl = e / (K / 4), qq = e % (K / 4);
-            const long r = min(r0 + rl, (long)rows - 1);
-            const float4 v = *reinterpret_cast<const float4*>(&h[r * K + qq * 4]);
-            const int chunk = qq / (KC / 4), j4 = qq % (KC / 4);
-            *reinterpret_cast<float4*>(&as[(chunk * 64 + rl) * KP + j4 * 4]) = v;
-        }
-        __syncthreads();
-        f32x4 acc[4];
+template <int RP>
+__device__ __forceinline__ void store_split4(_Float16* ahi, _Float16* alo, int row, int k0, float4 v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    f16x4 h4, l4;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{bz[nt], bz[nt], bz[nt], bz[nt]};
-        const float* arow = &as[(g4 * 64 + wave * 16 + l15) * KP];
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        h4[i] = h;
+        l4[i] = (_Float16)((x[i] - (float)h) * PW_SPLIT);
+    }
+    const int idx = a_index<RP>(row, k0);
+    *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
+    *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
+}
+
+// bias + A[m-tile rows] * W[n-tile]  for K = 32*KS; wh/wl = hi/lo B fragments of this wave's n-tile
+template <int RP, int KS>
+__device__ __forceinline__ f32x4 mma_tile(const _Float16* ahi, const _Float16* alo, int m, int g4, int l15,
+                                          const f16x8 (&wh)[KS], const f16x8 (&wl)[KS], float bias) {
+    f32x4 am = f32x4{bias, bias, bias, bias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int qq = 0; qq < KC / 4; ++qq) {
-            const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+    for (int ks = 0; ks < KS; ++ks) {
+        const int idx = ((ks * 4 + g4) * RP + m * 16 + l15) * 8;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
+        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
+    }
+    return am + ac * (1.0f / PW_SPLIT);
+}
+
+// weight image: [n-tile][kstep][lane][hi 8 | lo 8] fp16 (weights.py: pack_linear_f16x3)
+template <int KS>
+__device__ __forceinline__ void load_w(const _Float16* __restrict__ w_pk, int nt, int lane, f16x8 (&wh)[KS],
+                                       f16x8 (&wl)[KS]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wreg[nt][qq * 4 + j], acc[nt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cs[(wave * 16 + g4 * 4 + r) * CP + nt * 16 + l15] = acc[nt][r];
-        __syncthreads();
-        // residual add + coalesced store: each wave writes its own 16 rows
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = lane + 64 * i, rr = e >> 4, qq = e & 15;
-            const long r = r0 + wave * 16 + rr;
-            if (r < rows) {
-                const float4 cv = *reinterpret_cast<const float4*>(&cs[(wave * 16 + rr) * CP + qq * 4]);
-                const float4 rv = *reinterpret_cast<const float4*>(&res[r * C + qq * 4]);
-                *reinterpret_cast<float4*>(&out[r * C + qq * 4]) =
-                    make_float4(cv.x + rv.x, cv.y + rv.y, cv.z + rv.z, cv.w + rv.w);
-            }
-        }
-        // the next iteration's staging barrier orders these LDS reads before cs is rewritten
+    for (int ks = 0; ks < KS; ++ks) {
+        const _Float16* p = w_pk + ((long)(nt * KS + ks) * 64 + lane) * 16;
+        wh[ks] = *reinterpret_cast<const f16x8*>(p);
+        wl[ks] = *reinterpret_cast<const f16x8*>(p + 8);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// shared piece: stage one frame [97 x 64] into the 4-chunk LDS image used as MFMA A operand (K = 64)
+// out[r][0:64] = res[r][0:64] + bias + sum_k h[r][k] * W[o][k]       K in {64, 128}; 64-row tiles
 // ------------------------------------------------------------------------------------------------------
-constexpr int FR_MT = 7;                  // 7 M tiles cover 97 rows (112)
-constexpr int FR_KP = 20;                 // 16-float k-chunk + 4 pad
+template <int K>
+__global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h, const _Float16* __restrict__ w_pk,
+                                                    const float* __restrict__ bias, const float* __restrict__ res,
+                                                    float* __restrict__ out, int rows) {
+    constexpr int KS = K / 32, RP = 64, CP = C + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[KS * 4 * RP * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[KS * 4 * RP * 8];
+    __shared__ __attribute__((aligned(16))) float cs[RP * CP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
-__device__ __forceinline__ void stage_frame(const float* __restrict__ src, float* as, int tid) {
-    for (int e = tid; e < NF * 16; e += 256) {
-        const int rl = e >> 4, qq = e & 15;
-        const float4 v = *reinterpret_cast<const float4*>(&src[rl * C + qq * 4]);
-        *reinterpret_cast<float4*>(&as[((qq >> 2) * (FR_MT * 16) + rl) * FR_KP + (qq & 3) * 4]) = v;
+    f16x8 wh[KS], wl[KS];
+    load_w<KS>(w_pk, wave, lane, wh, wl);              // wave w owns output columns 16w .. 16w+15
+    const float bz = bias[wave * 16 + l15];
+
+    const int ntiles = (rows + RP - 1) / RP;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long r0 = (long)tile * RP;
+        constexpr int NLD = RP * (K / 4) / 256;
+        float4 stg[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {                // all global loads of the tile in flight
+            const int e = tid + 256 * i;
+            const long r = min(r0 + e / (K / 4), (long)rows - 1);
+            stg[i] = *reinterpret_cast<const float4*>(&h[r * K + (e % (K / 4)) * 4]);
+        }
+        // residual rows: issue the loads now, they land while the MFMAs run
+        float4 rv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const long r = min(r0 + (e >> 4), (long)rows - 1);
+            rv[i] = *reinterpret_cast<const float4*>(&res[r * C + (e & 15) * 4]);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 256 * i;
+            store_split4<RP>(ahi, alo, e / (K / 4), (e % (K / 4)) * 4, stg[i]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < RP / 16; ++m) {
+            const f32x4 acc = mma_tile<RP, KS>(ahi, alo, m, g4, l15, wh, wl, bz);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[(m * 16 + g4 * 4 + r) * CP + wave * 16 + l15] = acc[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, rr = e >> 4, qq = e & 15;
+            const long r = r0 + rr;
+            if (r < rows) {
+                const float4 cv = *reinterpret_cast<const float4*>(&cs[rr * CP + qq * 4]);
+                *reinterpret_cast<float4*>(&out[r * C + qq * 4]) =
+                    make_float4(cv.x + rv[i].x, cv.y + rv[i].y, cv.z + rv[i].z, cv.w + rv[i].w);
+            }
+        }
+        // the next tile's staging barrier orders these cs reads before cs is rewritten
     }
-    for (int e = tid; e < (FR_MT * 16 - NF) * 16; e += 256) {      // zero the 15 padding rows
-        const int rl = NF + (e >> 4), qq = e & 15;
-        *reinterpret_cast<float4*>(&as[((qq >> 2) * (FR_MT * 16) + rl) * FR_KP + (qq & 3) * 4]) =
-            make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// frame staging shared by the two frame kernels: [97 x 64] fp32 -> hi/lo fp16 A image (rows padded to 112)
+// ------------------------------------------------------------------------------------------------------
+constexpr int FR_RP = 112;
+constexpr int FR_A = 2 * 4 * FR_RP * 8;    // halves per image (K = 64 -> 2 k-steps)
+constexpr int FR_NLD = (NF * 16 + 255) / 256;
+
+__device__ __forceinline__ void frame_load(const float* __restrict__ src, int tid, float4 (&stg)[FR_NLD]) {
+#pragma unroll
+    for (int i = 0; i < FR_NLD; ++i) {
+        const int e = min(tid + 256 * i, NF * 16 - 1);
+        stg[i] = *reinterpret_cast<const float4*>(&src[(e >> 4) * C + (e & 15) * 4]);
+    }
+}
+__device__ __forceinline__ void frame_store(_Float16* ahi, _Float16* alo, int tid, const float4 (&stg)[FR_NLD]) {
+#pragma unroll
+    for (int i = 0; i < FR_NLD; ++i) {
+        const int e = tid + 256 * i;
+        if (e < NF * 16) store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[i]);
+    }
+}
+// rows 97..111 of the image feed only accumulator rows that are dropped, but must hold finite numbers
+__device__ __forceinline__ void frame_zero_pad(_Float16* ahi, _Float16* alo, int tid) {
+    for (int e = tid; e < 2 * 4 * (FR_RP - NF) * 8; e += 256) {
+        const int j = e & 7, row = NF + (e >> 3) % (FR_RP - NF), blk = (e >> 3) / (FR_RP - NF);
+        ahi[(blk * FR_RP + row) * 8 + j] = (_Float16)0.f;
+        alo[(blk * FR_RP + row) * 8 + j] = (_Float16)0.f;
     }
 }
 
@@ -105,205 +172,209 @@ template <int D>
 __device__ __forceinline__ void ln_head(const float* ys, int yp, int col0, const float* __restrict__ gw,
                                         const float* __restrict__ gb, float* __restrict__ dst, int ld, int lane) {
     constexpr int N = NF * D;
+    constexpr int IT = (N + 63) / 64;              // 10 (Q/K) or 25 (V) values per lane, kept in registers
+    float val[IT];
     float s = 0.f;
-    for (int i = lane; i < N; i += 64) s += ys[(i / D) * yp + col0 + (i % D)];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = lane + 64 * k;
+        const int ic = i < N ? i : N - 1;
+        val[k] = ys[(ic / D) * yp + col0 + (ic % D)];
+        if (i < N) s += val[k];
+    }
     const float mean = wave_sum(s) * (1.0f / N);
     float v = 0.f;
-    for (int i = lane; i < N; i += 64) { const float dv = ys[(i / D) * yp + col0 + (i % D)] - mean; v += dv * dv; }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const float dv = val[k] - mean;
+        if (lane + 64 * k < N) v += dv * dv;
+    }
     const float rstd = rsqrtf(wave_sum(v) * (1.0f / N) + LN_EPS);
-    for (int i = lane; i < ld; i += 64) {
-        float o = 0.f;
-        if (i < N) o = (ys[(i / D) * yp + col0 + (i % D)] - mean) * rstd * gw[i] + gb[i];
-        dst[i] = o;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {                 // fully unrolled: the affine loads of all slots are in flight together
+        const int i = lane + 64 * k;
+        const int ic = i < N ? i : N - 1;
+        const float o = (val[k] - mean) * rstd * gw[ic] + gb[ic];
+        if (i < ld) dst[i] = i < N ? o : 0.f;      // pad columns (q/kx) stay 0
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // Q/K/V projection + PReLU + per-head LayerNorm over (f,e); persistent workgroups, grid-stride over frames
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict__ y, const float* __restrict__ w_pk,
+__global__ void __launch_bounds__(256) k_qkv_proj_ln(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slopes,
                                                      const float* __restrict__ lnq_w, const float* __restrict__ lnq_b,
                                                      const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
                                                      const float* __restrict__ lnv_w, const float* __restrict__ lnv_b,
                                                      float* __restrict__ q, float* __restrict__ kx,
                                                      float* __restrict__ vx, int T, int nframes) {
-    constexpr int NT = NQKV / 16;         // 7 N tiles
     constexpr int YP = NQKV + 1;          // 113: odd stride -> conflict-free column walks in the LN phase
-    __shared__ __attribute__((aligned(16))) float as[4 * FR_MT * 16 * FR_KP];
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ float ys[NF * YP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
-    float wreg[NT][16];                   // weights loaded once per persistent workgroup
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) wreg[nt][ks] = w_pk[(nt * 16 + ks) * 64 + lane];
+    // wave w owns output-column tiles w and w+4 (of 7): Q|K|V columns 16w.. and 64+16w..
+    f16x8 wh0[2], wl0[2], wh1[2], wl1[2];
+    load_w<2>(w_pk, wave, lane, wh0, wl0);
+    const bool two = wave + 4 < NQKV / 16;
+    load_w<2>(w_pk, two ? wave + 4 : wave, lane, wh1, wl1);
+    const int c0 = wave * 16 + l15, c1 = c0 + 64;
+    const float bz0 = bias[c0], bz1 = bias[two ? c1 : c0];
     const float sq = slopes[0], sk = slopes[1], sv = slopes[2];
+    const float a0 = c0 < NH * E ? sq : (c0 < 2 * NH * E ? sk : sv);      // PReLU slope of column c0; c1 is always V
 
-  for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
-    const int b = fr / T, t = fr % T;
-    stage_frame(y + (long)fr * NF * C, as, tid);
-    __syncthreads();                      // also orders the previous frame's LDS reads of `ys`
+    frame_zero_pad(ahi, alo, tid);
+    float4 stg[FR_NLD];
+    if ((int)blockIdx.x < nframes) frame_load(y + (long)blockIdx.x * NF * C, tid, stg);
+    for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
+        const int b = fr / T, t = fr % T;
+        frame_store(ahi, alo, tid, stg);
+        __syncthreads();                      // image complete; also orders the previous frame's reads of `ys`
+        if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
-    for (int m = wave; m < FR_MT; m += 4) {
-        f32x4 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float bz = bias[nt * 16 + l15];
-            acc[nt] = f32x4{bz, bz, bz, bz};
-        }
-        const float* arow = &as[(g4 * (FR_MT * 16) + m * 16 + l15) * FR_KP];
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wreg[nt][qq * 4 + j], acc[nt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = nt * 16 + l15;
-            const float a = col < NH * E ? sq : (col < 2 * NH * E ? sk : sv);
+        for (int m = 0; m < FR_RP / 16; ++m) {
+            const f32x4 r0 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh0, wl0, bz0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m * 16 + g4 * 4 + r;
-                if (row < NF) ys[row * YP + col] = prelu_f(acc[nt][r], a);
+                if (row < NF) ys[row * YP + c0] = prelu_f(r0[r], a0);
+            }
+            if (two) {
+                const f32x4 r1 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh1, wl1, bz1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m * 16 + g4 * 4 + r;
+                    if (row < NF) ys[row * YP + c1] = prelu_f(r1[r], sv);
+                }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // per-head LayerNorm: wave w normalises head w of Q, K and V; flat index = f*D + e (F-major, e-minor)
-    const int hd = wave;
-    const long bh = (long)b * NH + hd;
-    ln_head<E>(ys, YP, hd * E, lnq_w, lnq_b, q + (bh * T + t) * LDQK, LDQK, lane);
-    ln_head<E>(ys, YP, NH * E + hd * E, lnk_w, lnk_b, kx + (bh * (T + HIST) + HIST + t) * LDQK, LDQK, lane);
-    ln_head<VD>(ys, YP, 2 * NH * E + hd * VD, lnv_w, lnv_b, vx + (bh * (T + HIST) + HIST + t) * DV, DV, lane);
-  }
+        // per-head LayerNorm: wave w normalises head w of Q, K and V; flat index = f*D + e (F-major, e-minor)
+        const int hd = wave;
+        const long bh = (long)b * NH + hd;
+        ln_head<E>(ys, YP, hd * E, lnq_w, lnq_b, q + (bh * T + t) * LDQK, LDQK, lane);
+        ln_head<E>(ys, YP, NH * E + hd * E, lnk_w, lnk_b, kx + (bh * (T + HIST) + HIST + t) * LDQK, LDQK, lane);
+        ln_head<VD>(ys, YP, 2 * NH * E + hd * VD, lnv_w, lnv_b, vx + (bh * (T + HIST) + HIST + t) * DV, DV, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// attn_concat_proj + LN over (f,c) + residual (+ speaker gain);  grid (T, B), one frame per workgroup
+// attn_concat_proj + LN over (f,c) + residual (+ speaker gain); persistent, grid-stride over frames
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict__ merged, const float* __restrict__ w_pk,
+__global__ void __launch_bounds__(256) k_proj_ln_res(const float* __restrict__ merged, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slope,
                                                      const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                      const float* __restrict__ y2, const float* __restrict__ gain,
                                                      float* __restrict__ out, int T, int nframes) {
     constexpr int YP = C + 4;
-    __shared__ __attribute__((aligned(16))) float as[4 * FR_MT * 16 * FR_KP];
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float ys[NF * YP];
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
-    float wreg[4][16];                    // weights loaded once per persistent workgroup
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) wreg[nt][ks] = w_pk[(nt * 16 + ks) * 64 + lane];
+    f16x8 wh[2], wl[2];
+    load_w<2>(w_pk, wave, lane, wh, wl);   // wave w owns output channels 16w .. 16w+15
+    const float bz = bias[wave * 16 + l15];
     const float a = slope[0];
     // LayerNorm affine of this thread's fixed float4 slots, resident for all frames of the persistent loop
-    constexpr int NSLOT = (NF * C / 4 + 255) / 256;      // 7
+    constexpr int N = NF * C, N4 = N / 4;
+    constexpr int NSLOT = (N4 + 255) / 256;      // 7
     float4 pw[NSLOT], pb[NSLOT];
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
-        const int i = min(tid + 256 * k, NF * C / 4 - 1);
+        const int i = min(tid + 256 * k, N4 - 1);
         pw[k] = *reinterpret_cast<const float4*>(&lnw[i * 4]);
         pb[k] = *reinterpret_cast<const float4*>(&lnb[i * 4]);
     }
 
-  for (int fidx = blockIdx.x; fidx < nframes; fidx += gridDim.x) {     // grid-stride over frames (b*T + t)
-    const int b = fidx / T;
-    const long fr = (long)fidx * NF * C;
-    stage_frame(merged + fr, as, tid);
-    __syncthreads();                      // also orders the previous frame's LDS reads of `ys`
+    frame_zero_pad(ahi, alo, tid);
+    float4 stg[FR_NLD];
+    if ((int)blockIdx.x < nframes) frame_load(merged + (long)blockIdx.x * N, tid, stg);
+    for (int fidx = blockIdx.x; fidx < nframes; fidx += gridDim.x) {     // grid-stride over frames (b*T + t)
+        const int b = fidx / T;
+        const long fr = (long)fidx * N;
+        frame_store(ahi, alo, tid, stg);
+        __syncthreads();                      // image complete; also orders the previous frame's reads of `ys`
+        if (fidx + (int)gridDim.x < nframes) frame_load(merged + (long)(fidx + gridDim.x) * N, tid, stg);
 
-    for (int m = wave; m < FR_MT; m += 4) {
-        f32x4 acc[4];
+        // residual rows of this frame: loads in flight during the MFMA + statistics phases
+        float4 rv[NSLOT];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const float bz = bias[nt * 16 + l15];
-            acc[nt] = f32x4{bz, bz, bz, bz};
-        }
-        const float* arow = &as[(g4 * (FR_MT * 16) + m * 16 + l15) * FR_KP];
+        for (int k = 0; k < NSLOT; ++k)
+            rv[k] = *reinterpret_cast<const float4*>(&y2[fr + (long)min(tid + 256 * k, N4 - 1) * 4]);
+
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wreg[nt][qq * 4 + j], acc[nt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int m = 0; m < FR_RP / 16; ++m) {
+            const f32x4 acc = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh, wl, bz);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m * 16 + g4 * 4 + r;
-                if (row < NF) ys[row * YP + nt * 16 + l15] = prelu_f(acc[nt][r], a);
+                if (row < NF) ys[row * YP + wave * 16 + l15] = prelu_f(acc[r], a);
             }
-    }
-    __syncthreads();
-
-    // joint LayerNorm over all 97*64 values of the frame (flat index f*64 + c), float4 granules
-    constexpr int N = NF * C, N4 = N / 4;
-    float s = 0.f;
-    for (int i = tid; i < N4; i += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(&ys[(i >> 4) * YP + (i & 15) * 4]);
-        s += v.x + v.y + v.z + v.w;
-    }
-    const float mean = block_sum_256(s, red) * (1.0f / N);
-    float vs = 0.f;
-    for (int i = tid; i < N4; i += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(&ys[(i >> 4) * YP + (i & 15) * 4]);
-        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-        vs += dx * dx + dy * dy + dz * dz + dw * dw;
-    }
-    const float rstd = rsqrtf(block_sum_256(vs, red) * (1.0f / N) + LN_EPS);
-#pragma unroll
-    for (int k = 0; k < NSLOT; ++k) {
-        const int i = tid + 256 * k;
-        if (i >= N4) break;
-        const float4 v = *reinterpret_cast<const float4*>(&ys[(i >> 4) * YP + (i & 15) * 4]);
-        const float4 gw = pw[k], gb = pb[k];
-        const float4 rv = *reinterpret_cast<const float4*>(&y2[fr + i * 4]);
-        float4 o;
-        o.x = rv.x + (v.x - mean) * rstd * gw.x + gb.x;
-        o.y = rv.y + (v.y - mean) * rstd * gw.y + gb.y;
-        o.z = rv.z + (v.z - mean) * rstd * gw.z + gb.z;
-        o.w = rv.w + (v.w - mean) * rstd * gw.w + gb.w;
-        if (gain) {
-            const float4 gv = *reinterpret_cast<const float4*>(&gain[(long)b * N + i * 4]);
-            o.x *= gv.x; o.y *= gv.y; o.z *= gv.z; o.w *= gv.w;
         }
-        *reinterpret_cast<float4*>(&out[fr + i * 4]) = o;
+        __syncthreads();
+
+        // joint LayerNorm over all 97*64 values of the frame (flat index f*64 + c), float4 granules
+        float4 v[NSLOT];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const int i = min(tid + 256 * k, N4 - 1);
+            v[k] = *reinterpret_cast<const float4*>(&ys[(i >> 4) * YP + (i & 15) * 4]);
+            if (tid + 256 * k < N4) s += v[k].x + v[k].y + v[k].z + v[k].w;
+        }
+        const float mean = block_sum_256(s, red) * (1.0f / N);
+        float vs = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+            if (tid + 256 * k < N4) vs += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+        const float rstd = rsqrtf(block_sum_256(vs, red) * (1.0f / N) + LN_EPS);
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < N4) {
+                float4 o;
+                o.x = rv[k].x + (v[k].x - mean) * rstd * pw[k].x + pb[k].x;
+                o.y = rv[k].y + (v[k].y - mean) * rstd * pw[k].y + pb[k].y;
+                o.z = rv[k].z + (v[k].z - mean) * rstd * pw[k].z + pb[k].z;
+                o.w = rv[k].w + (v[k].w - mean) * rstd * pw[k].w + pb[k].w;
+                if (gain) {
+                    const float4 gv = *reinterpret_cast<const float4*>(&gain[(long)b * N + i * 4]);
+                    o.x *= gv.x; o.y *= gv.y; o.z *= gv.z; o.w *= gv.w;
+                }
+                *reinterpret_cast<float4*>(&out[fr + i * 4]) = o;
+            }
+        }
     }
-  }
 }
 
 }  // namespace lh
 
-extern "C" int lh_linear_res(const float* h, const float* w_pk, const float* bias, const float* res, float* out,
+extern "C" int lh_linear_res(const float* h, const void* w_pk, const float* bias, const float* res, float* out,
                              int rows, int K, lh_stream_t stream) {
     using namespace lh;
     if (!h || !w_pk || !bias || !res || !out || rows <= 0) return LH_ERR_ARG;
     const int ntiles = (rows + 63) / 64;
-    const int grid = ntiles < 1024 ? ntiles : 1024;
+    const int grid = ntiles < 768 ? ntiles : 768;
     if (K == 128)
-        hipLaunchKernelGGL((k_linear_res<128>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w_pk, bias, res, out, rows);
+        hipLaunchKernelGGL((k_linear_res<128>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, (const _Float16*)w_pk,
+                           bias, res, out, rows);
     else if (K == 64)
-        hipLaunchKernelGGL((k_linear_res<64>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w_pk, bias, res, out, rows);
+        hipLaunchKernelGGL((k_linear_res<64>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, (const _Float16*)w_pk,
+                           bias, res, out, rows);
     else
         return LH_ERR_UNSUPPORTED;
     return check_launch();
 }
 
-extern "C" int lh_qkv_proj_ln(const float* y, const float* w_pk, const float* bias, const float* slopes,
+extern "C" int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const float* slopes,
                               const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
                               const float* lnv_w, const float* lnv_b, float* q, float* kx, float* vx, int B, int T,
                               lh_stream_t stream) {
@@ -312,18 +383,19 @@ extern "C" int lh_qkv_proj_ln(const float* y, const float* w_pk, const float* bi
         !vx || B <= 0 || T <= 0)
         return LH_ERR_ARG;
     const int nframes = B * T;
-    hipLaunchKernelGGL(k_qkv_proj_ln, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y, w_pk,
-                       bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, q, kx, vx, T, nframes);
+    hipLaunchKernelGGL(k_qkv_proj_ln, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y,
+                       (const _Float16*)w_pk, bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, q, kx, vx, T,
+                       nframes);
     return check_launch();
 }
 
-extern "C" int lh_proj_ln_res(const float* merged, const float* w_pk, const float* bias, const float* slope,
+extern "C" int lh_proj_ln_res(const float* merged, const void* w_pk, const float* bias, const float* slope,
                               const float* ln_w, const float* ln_b, const float* y2, const float* gain, float* out,
                               int B, int T, lh_stream_t stream) {
     using namespace lh;
     if (!merged || !w_pk || !bias || !slope || !ln_w || !ln_b || !y2 || !out || B <= 0 || T <= 0) return LH_ERR_ARG;
     const int nframes = B * T;
     hipLaunchKernelGGL(k_proj_ln_res, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, merged,
-                       w_pk, bias, slope, ln_w, ln_b, y2, gain, out, T, nframes);
+                       (const _Float16*)w_pk, bias, slope, ln_w, ln_b, y2, gain, out, T, nframes);
     return check_launch();
 }

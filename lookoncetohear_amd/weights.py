@@ -70,6 +70,22 @@ def pack_lstm_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo], dim=4).contiguous()             # [4,4,4,64,2,8]
 
 
+def pack_linear_f16x3(w: torch.Tensor) -> torch.Tensor:
+    """w [N, K] -> split-precision B image [N/16, K/32, 64 lanes, 2 (hi|lo), 8] fp16 for v_mfma_f32_16x16x32_f16:
+    lane l of (n-tile nt, k-step ks) holds W[nt*16 + (l & 15)][ks*32 + (l >> 4)*8 + j], j = 0..7."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0
+    dev = w.device
+    lane = torch.arange(64, device=dev)
+    nt = torch.arange(N // 16, device=dev)[:, None, None, None]
+    ks = torch.arange(K // 32, device=dev)[None, :, None, None]
+    j = torch.arange(8, device=dev)[None, None, None, :]
+    n = nt * 16 + (lane & 15)[None, None, :, None]
+    k = ks * 32 + (lane >> 4)[None, None, :, None] * 8 + j
+    hi, lo = split_f16(w.float()[n, k])
+    return torch.stack([hi, lo], dim=3).contiguous()
+
+
 def pack_block(sd: dict, pre: str) -> dict:
     g = lambda k: sd[pre + k].detach()
     out = {}
@@ -82,19 +98,19 @@ def pack_block(sd: dict, pre: str) -> dict:
     out["inter_w16"] = pack_lstm_f16x3(g("inter_rnn.weight_ih_l0"), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
-    out["intra_lin_w"], out["intra_lin_b"] = pack_linear(g("intra_linear.weight")), g("intra_linear.bias")
+    out["intra_lin_w"], out["intra_lin_b"] = pack_linear_f16x3(g("intra_linear.weight")), g("intra_linear.bias")
     out["inter_ln_w"], out["inter_ln_b"] = g("inter_norm.norm.weight"), g("inter_norm.norm.bias")
     out["inter_w"] = pack_lstm(g("inter_rnn.weight_ih_l0"), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["inter_b"] = g("inter_rnn.bias_ih_l0") + g("inter_rnn.bias_hh_l0")
-    out["inter_lin_w"], out["inter_lin_b"] = pack_linear(g("inter_linear.weight")), g("inter_linear.bias")
-    out["qkv_w"] = pack_linear(torch.cat([g("attn_conv_Q.0.weight"), g("attn_conv_K.0.weight"),
-                                          g("attn_conv_V.0.weight")], 0))
+    out["inter_lin_w"], out["inter_lin_b"] = pack_linear_f16x3(g("inter_linear.weight")), g("inter_linear.bias")
+    out["qkv_w"] = pack_linear_f16x3(torch.cat([g("attn_conv_Q.0.weight"), g("attn_conv_K.0.weight"),
+                                                g("attn_conv_V.0.weight")], 0))
     out["qkv_b"] = torch.cat([g("attn_conv_Q.0.bias"), g("attn_conv_K.0.bias"), g("attn_conv_V.0.bias")])
     out["qkv_slopes"] = torch.cat([g("attn_conv_Q.1.weight"), g("attn_conv_K.1.weight"), g("attn_conv_V.1.weight")])
     for nm in "QKV":
         out[f"ln{nm.lower()}_w"] = g(f"attn_conv_{nm}.3.norm.weight")
         out[f"ln{nm.lower()}_b"] = g(f"attn_conv_{nm}.3.norm.bias")
-    out["proj_w"], out["proj_b"] = pack_linear(g("attn_concat_proj.0.weight")), g("attn_concat_proj.0.bias")
+    out["proj_w"], out["proj_b"] = pack_linear_f16x3(g("attn_concat_proj.0.weight")), g("attn_concat_proj.0.bias")
     out["proj_slope"] = g("attn_concat_proj.1.weight")
     out["proj_ln_w"], out["proj_ln_b"] = g("attn_concat_proj.3.norm.weight"), g("attn_concat_proj.3.norm.bias")
     return {k: (v.contiguous() if v.dtype == torch.float16 else v.contiguous().float()) for k, v in out.items()}

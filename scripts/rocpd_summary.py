@@ -9,6 +9,8 @@ import sys
 
 
 def short(name):
+    if name.startswith("_ZN2lh12k_ln_lstm_h3ILi"):
+        return "lh::k_ln_lstm_h3<%s>" % name[len("_ZN2lh12k_ln_lstm_h3ILi")]
     return name.split("(")[0].replace("void ", "")[:100]
 
 
@@ -39,7 +41,7 @@ def main(db, out, pmc=False):
         w.writerow(["kernel", "counter", "dispatches", "avg_per_dispatch"])
         n = 0
         for k, cn, cnt, v in c.execute(q):
-            if "lh::" in k:
+            if "lh::" in k or "_ZN2lh" in k:
                 w.writerow([short(k), cn, cnt, f"{v:.6g}"])
                 n += 1
         print("wrote", out, n, "rows")
