@@ -35,7 +35,9 @@ enum {
  *   LH_GEMM_F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32); w_pk = fp32 image  [dirs][4][4][32][64]
  *   LH_GEMM_F16X3 split precision: each fp32 operand = fp16 hi + 2^-11 * fp16 lo, three fp16 MFMAs
  *                 (hi*hi, hi*lo, lo*hi) accumulated in fp32 (~22 mantissa bits);
- *                 w_pk = fp16 image [dirs][4 waves][4 gates][4 ksteps][64 lanes][hi 8 | lo 8]  */
+ *                 w_pk = fp16 image [dirs][4 waves][4 gates][4 ksteps][64 lanes][hi 8 | lo 8] of
+ *                 [W_ih * ln_w | W_hh] and b_sum = b_ih + b_hh + W_ih ln_b: the LayerNorm affine is folded into
+ *                 the image (weights.py pack_block), the kernel only standardises x; ln_w/ln_b are ignored  */
 enum { LH_GEMM_F32 = 0, LH_GEMM_F16X3 = 1 };
 
 /* ABI version of this header; bumped on any signature change. */

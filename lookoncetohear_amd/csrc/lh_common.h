@@ -40,17 +40,27 @@ __device__ __forceinline__ float tanh_f(float x) {
 }
 __device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
 
-// sum over the 64 lanes of a wave (every lane gets the total)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// sum over the 64 lanes of a wave (every lane gets the total): 4 DPP row steps + 2 cross-row shuffles
+__device__ __forceinline__ float wave_sum(float v);
+// v + (v rotated right by N lanes inside each aligned row of 16 lanes): one VALU op with a DPP modifier
+// (row_ror:N = dpp_ctrl 0x120+N) instead of a ds_bpermute round trip through the LDS crossbar.
+template <int N>
+__device__ __forceinline__ float row_ror_add(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, r);
 }
-// sum over aligned groups of 16 lanes
+// sum over aligned groups of 16 lanes (every lane of the group gets the total)
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = row_ror_add<8>(v);
+    v = row_ror_add<4>(v);
+    v = row_ror_add<2>(v);
+    return row_ror_add<1>(v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v = group16_sum(v);
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
 }
 
 // Sum `v` over all threads of a 256-thread workgroup; `red` is a >= 4-float LDS scratch.

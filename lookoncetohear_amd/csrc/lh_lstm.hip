@@ -242,8 +242,7 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
     for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + wave * 16 + l15];
 
     const int q = tid & 15;
-    const float4 gw = *reinterpret_cast<const float4*>(&lnw[q * 4]);
-    const float4 gb = *reinterpret_cast<const float4*>(&lnb[q * 4]);
+    // the LayerNorm affine is folded into the packed image: W_ih' = W_ih * ln_w, b' = b + W_ih ln_b (weights.py)
 
     auto load_x = [&](int it, float4 (&xr)[MT]) {
         const int p = step_pos(it);
@@ -273,8 +272,7 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
             v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
             const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
             const float rstd = rsqrtf(var + LN_EPS);
-            store_split4(buf, rl, q * 4, v.x * rstd * gw.x + gb.x, v.y * rstd * gw.y + gb.y, v.z * rstd * gw.z + gb.z,
-                         v.w * rstd * gw.w + gb.w);
+            store_split4(buf, rl, q * 4, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
         }
     };
     auto flush_h = [&](int buf, int it) {
@@ -390,6 +388,207 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Software-pipelined split-precision kernel (NS = 16 sequences per workgroup): the gate pre-activations are
+//     gates_t = [LN(x_t) W_ih^T + b]  +  h_{t-1} W_hh^T
+// and only the second term sits on the recurrence.  The x-term of step t+1 is computed inside step t, in the
+// same basic block as the cell update of step t, so its 24 MFMAs run on the matrix pipe underneath the ~190
+// VALU instructions (exp/rcp/LayerNorm/splits) of the cell update; the post-barrier critical path of a step
+// shrinks to: read h fragments -> 24 MFMAs -> cell update -> write h.  x tiles are triple-buffered (tile t+2
+// is normalised and written while tile t+1 is consumed), LDS images use the swizzled block layout of
+// lh_common.h (conflict-free fragment reads and row-major writes).
+// ------------------------------------------------------------------------------------------------------
+constexpr int LP_RP = 16;                        // rows per A image
+constexpr int LP_XI = 2 * 4 * LP_RP * 8;         // halves per x (or h) image: K = 64 -> 2 k-steps x 4 lane groups
+
+__device__ __forceinline__ int lp_slot(int blk, int row) { return (blk * LP_RP + (row ^ (blk & 7))) * 8; }
+__device__ __forceinline__ int lp_index(int row, int k) { return lp_slot((k >> 5) * 4 + ((k >> 3) & 3), row) + (k & 7); }
+
+__global__ void __launch_bounds__(256, 2) k_ln_lstm_p(const float* __restrict__ x, const float* __restrict__ lnw,
+                                                      const float* __restrict__ lnb, const _Float16* __restrict__ w_pk,
+                                                      const float* __restrict__ b_sum, const float* __restrict__ h0,
+                                                      const float* __restrict__ c0, float* __restrict__ hN,
+                                                      float* __restrict__ cN, float* __restrict__ h_out, int nseq,
+                                                      int nstep, int sdiv, int so, int si, int ps, int ldh) {
+    constexpr int NS = 16;
+    __shared__ __attribute__((aligned(16))) _Float16 xhi[3 * LP_XI], xlo[3 * LP_XI];
+    __shared__ __attribute__((aligned(16))) _Float16 hhi[2 * LP_XI], hlo[2 * LP_XI];
+    __shared__ __attribute__((aligned(16))) float hf[2 * NS * LH_HP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y;
+    const int s0 = blockIdx.x * NS;
+    const int g4 = lane >> 4, l15 = lane & 15;
+
+    auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
+    auto step_pos = [&](int it) -> int { it = min(it, nstep - 1); return dir ? (nstep - 1 - it) : it; };
+
+    // resident weights, image [dir][wave][gate][ks][lane][hi8|lo8]; ks 0,1 = W_ih (x), ks 2,3 = W_hh (h)
+    f16x8 wh[4][4], wl[4][4];
+    {
+        const _Float16* wp = w_pk + ((long)(dir * 4 + wave) * 16 * 64 + lane) * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wh[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16);
+                wl[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16 + 8);
+            }
+    }
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + wave * 16 + l15];
+
+    // row-wise role: 16 lanes per 64-float row, one float4 each
+    const int q = tid & 15, rl = tid >> 4;
+    const int sr = min(s0 + rl, nseq - 1);
+    // the LayerNorm affine is folded into the packed image: W_ih' = W_ih * ln_w, b' = b + W_ih ln_b (weights.py)
+
+    auto load_x = [&](int it) -> float4 {
+        return *reinterpret_cast<const float4*>(&x[row_of(sr, step_pos(it)) * C + q * 4]);
+    };
+    auto store_split = [&](_Float16* phi, _Float16* plo, int row, int k0, float a, float b, float c, float d) {
+        const float v[4] = {a, b, c, d};
+        f16x4 h4, l4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const _Float16 th = (_Float16)v[i];
+            h4[i] = th;
+            l4[i] = (_Float16)((v[i] - (float)th) * SPLIT_SCALE);
+        }
+        const int idx = lp_index(row, k0);
+        *reinterpret_cast<f16x4*>(&phi[idx]) = h4;
+        *reinterpret_cast<f16x4*>(&plo[idx]) = l4;
+    };
+    auto norm_store_x = [&](int buf, float4 v) {
+        const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+        const float rstd = rsqrtf(var + LN_EPS);
+        store_split(xhi + buf * LP_XI, xlo + buf * LP_XI, rl, q * 4, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
+    };
+    // gates_x = bias + LN(x) W_ih^T for the tile in x buffer `buf` (24 MFMAs, no dependence on the recurrence)
+    auto x_gates = [&](int buf, f32x4 (&gx)[4]) {
+        f32x4 am[4], ac[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            am[g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
+            ac[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int idx = buf * LP_XI + lp_slot(ks * 4 + g4, l15);
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&xhi[idx]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&xlo[idx]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) am[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], am[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], ac[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], ac[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gx[g] = am[g] + ac[g] * (1.0f / SPLIT_SCALE);
+    };
+    auto flush_h = [&](int buf, int it) {          // fp32 h of step `it` -> global, coalesced 256-byte rows
+        if (s0 + rl < nseq)
+            *reinterpret_cast<float4*>(&h_out[row_of(s0 + rl, step_pos(it)) * ldh + dir * H + q * 4]) =
+                *reinterpret_cast<const float4*>(&hf[(buf * NS + rl) * LH_HP + q * 4]);
+    };
+
+    // ---- prologue: x tiles 0 and 1, initial state, gates_x of step 0
+    float creg[4];
+    {
+        norm_store_x(0, load_x(0));
+        norm_store_x(1, load_x(1));
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)sr * H + q * 4]);
+        store_split(hhi, hlo, rl, q * 4, hv.x, hv.y, hv.z, hv.w);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = min(s0 + g4 * 4 + r, nseq - 1);
+            creg[r] = c0 ? c0[(long)s * H + wave * 16 + l15] : 0.0f;
+        }
+    }
+    __syncthreads();
+    f32x4 gx[4];
+    x_gates(0, gx);
+    float4 xr = load_x(2);
+
+    const int unit = wave * 16 + l15;
+    for (int it = 0; it < nstep; ++it) {
+        const int cur = it & 1, nxt = cur ^ 1;
+        if (it > 0) flush_h(cur, it - 1);
+
+        // recurrent term: h_{t-1} W_hh^T on top of the precomputed gates_x (k-steps 2,3 of the weight image)
+        f32x4 am[4], ac[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { am[g] = gx[g]; ac[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int idx = cur * LP_XI + lp_slot(ks * 4 + g4, l15);
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&hhi[idx]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&hlo[idx]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) am[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][2 + ks], am[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][2 + ks], ac[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][2 + ks], ac[g], 0, 0, 0);
+        }
+
+        // gates_x of step t+1 (tile written one step ago): independent MFMAs the scheduler can sink under the
+        // VALU work below.  After the last step the tile is stale but finite and the result is unused.
+        f32x4 gxn[4];
+        x_gates((it + 1) % 3, gxn);
+
+        // cell update, lane-local: accumulator reg r <-> sequence row g4*4 + r, hidden unit wave*16 + l15
+        constexpr float INV = 1.0f / SPLIT_SCALE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = sigmoid_f(am[0][r] + ac[0][r] * INV);
+            const float fg = sigmoid_f(am[1][r] + ac[1][r] * INV);
+            const float gg = tanh_f(am[2][r] + ac[2][r] * INV);
+            const float og = sigmoid_f(am[3][r] + ac[3][r] * INV);
+            const float cc = fg * creg[r] + ig * gg;
+            creg[r] = cc;
+            const float hv = og * tanh_f(cc);
+            const int row = g4 * 4 + r;
+            const _Float16 th = (_Float16)hv;
+            const int idx = nxt * LP_XI + lp_index(row, unit);
+            hhi[idx] = th;
+            hlo[idx] = (_Float16)((hv - (float)th) * SPLIT_SCALE);
+            hf[(nxt * NS + row) * LH_HP + unit] = hv;
+        }
+        // x tile of step t+2, then fetch the row of step t+3 (clamped past the end: harmless rewrites)
+        norm_store_x((it + 2) % 3, xr);
+        xr = load_x(it + 3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gx[g] = gxn[g];
+        __syncthreads();
+    }
+
+    const int last = nstep & 1;
+    flush_h(last, nstep - 1);
+    if (hN && s0 + rl < nseq)
+        *reinterpret_cast<float4*>(&hN[(long)(s0 + rl) * H + q * 4]) =
+            *reinterpret_cast<const float4*>(&hf[(last * NS + rl) * LH_HP + q * 4]);
+    if (cN) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = s0 + g4 * 4 + r;
+            if (s < nseq) cN[(long)s * H + wave * 16 + l15] = creg[r];
+        }
+    }
+}
+
+static int launch_lstm_p(const float* x, const float* lnw, const float* lnb, const void* w_pk, const float* b_sum,
+                         const float* h0, const float* c0, float* hN, float* cN, float* h_out, int nseq, int nstep,
+                         int ndir, int sdiv, int so, int si, int ps, int ldh, hipStream_t st) {
+    hipLaunchKernelGGL(k_ln_lstm_p, dim3((nseq + 15) / 16, ndir), dim3(256), 0, st, x, lnw, lnb, (const _Float16*)w_pk,
+                       b_sum, h0, c0, hN, cN, h_out, nseq, nstep, sdiv, so, si, ps, ldh);
+    return check_launch();
+}
+
 template <int MT>
 static int launch_lstm_h3(const float* x, const float* lnw, const float* lnb, const void* w_pk, const float* b_sum,
                           const float* h0, const float* c0, float* hN, float* cN, float* h_out, int nseq, int nstep,
@@ -413,7 +612,7 @@ static int launch_lstm(const float* x, const float* lnw, const float* lnb, const
 }  // namespace lh
 
 namespace lh {
-static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto)
+static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [2] 1 = un-pipelined f16x3 kernel
 }
 extern "C" int lh_set_tuning(int key, int value) {
     if (key < 0 || key >= 4) return LH_ERR_ARG;
@@ -428,6 +627,9 @@ extern "C" int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* 
     // sequence s = frame (b,t); step p = frequency bin; row(s,p) = s*97 + p
     const int mt = g_tune[0] ? g_tune[0] : (mode == LH_GEMM_F16X3 ? 1 : (n_frames >= 8192 ? 2 : 1));
     if (mode == LH_GEMM_F16X3) {
+        if (mt == 1 && g_tune[2] == 0)
+            return launch_lstm_p(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1,
+                                 NF, 0, 1, 2 * H, (hipStream_t)stream);
         if (mt == 2)
             return launch_lstm_h3<2>(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF,
                                      2, 1, NF, 0, 1, 2 * H, (hipStream_t)stream);
@@ -454,6 +656,9 @@ extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* 
     const int nseq = B * NF;
     const int mt = g_tune[1] ? g_tune[1] : (nseq >= 32768 ? 2 : 1);
     if (mode == LH_GEMM_F16X3) {
+        if (mt == 1 && g_tune[2] == 0)
+            return launch_lstm_p(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
+                                 (hipStream_t)stream);
         if (mt == 2)
             return launch_lstm_h3<2>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
                                      (hipStream_t)stream);

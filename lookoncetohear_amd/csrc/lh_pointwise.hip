@@ -22,11 +22,17 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr float PW_SPLIT = 2048.0f;
 
-// A-operand LDS image for v_mfma_f32_16x16x32_f16: [kstep][16-lane group][row][8 halves]; a lane's 16 bytes of
-// consecutive rows are consecutive 16-byte slots -> conflict-free ds_read_b128, no padding.
+// A-operand LDS image for v_mfma_f32_16x16x32_f16: [block = kstep*4 + 16-lane group][row slot][8 halves].
+// Reads: a lane's 16 bytes of consecutive rows are consecutive 16-byte slots.  Writes come row-major from the
+// coalesced global loads (16 lanes = one row = 8 blocks x 2 halves), and the block stride is a multiple of
+// 128 bytes, so the row slot is XOR-swizzled with the block index: the 8 blocks of one row land in 8 different
+// slots (conflict-free ds_write_b64), while within any ds_read_b128 lane group the XOR only permutes rows
+// inside aligned groups of 4 (or swaps the two halves of the group), which keeps the reads conflict-free.
+template <int RP>
+__device__ __forceinline__ int a_slot(int blk, int row) { return (blk * RP + (row ^ (blk & 7))) * 8; }
 template <int RP>
 __device__ __forceinline__ int a_index(int row, int k) {
-    return (((k >> 5) * 4 + ((k >> 3) & 3)) * RP + row) * 8 + (k & 7);
+    return a_slot<RP>((k >> 5) * 4 + ((k >> 3) & 3), row) + (k & 7);
 }
 
 template <int RP>
@@ -51,7 +57,7 @@ __device__ __forceinline__ f32x4 mma_tile(const _Float16* ahi, const _Float16* a
     f32x4 am = f32x4{bias, bias, bias, bias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const int idx = ((ks * 4 + g4) * RP + m * 16 + l15) * 8;
+        const int idx = a_slot<RP>(ks * 4 + g4, m * 16 + l15);
         const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
         const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
         am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
@@ -159,50 +165,46 @@ __device__ __forceinline__ void frame_store(_Float16* ahi, _Float16* alo, int ti
 }
 // rows 97..111 of the image feed only accumulator rows that are dropped, but must hold finite numbers
 __device__ __forceinline__ void frame_zero_pad(_Float16* ahi, _Float16* alo, int tid) {
-    for (int e = tid; e < 2 * 4 * (FR_RP - NF) * 8; e += 256) {
-        const int j = e & 7, row = NF + (e >> 3) % (FR_RP - NF), blk = (e >> 3) / (FR_RP - NF);
-        ahi[(blk * FR_RP + row) * 8 + j] = (_Float16)0.f;
-        alo[(blk * FR_RP + row) * 8 + j] = (_Float16)0.f;
-    }
+    for (int e = tid; e < (FR_RP - NF) * 16; e += 256)
+        store_split4<FR_RP>(ahi, alo, NF + (e >> 4), (e & 15) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-// One wave: LayerNorm over the NF*D values ys[f][col0 + e] (flat index f*D + e), affine per flat index, written
-// to dst[0..ld) (columns >= NF*D are zero padding).  D is compile-time so the index split is shifts / mul-shift.
+// One wave: LayerNorm over the NF*D values ys[f][col0 + e] (flat index i = f*D + e), affine per flat index, written
+// to dst[0..ld) (columns >= NF*D are zero padding).  Slot k of a lane is i = lane + 64k; out-of-range slots are
+// predicated (not clamped) so that for D = 16 every address is `base + k * constant` (immediate offsets, no
+// per-slot address registers kept live across the persistent frame loop).
 template <int D>
 __device__ __forceinline__ void ln_head(const float* ys, int yp, int col0, const float* __restrict__ gw,
                                         const float* __restrict__ gb, float* __restrict__ dst, int ld, int lane) {
     constexpr int N = NF * D;
-    constexpr int IT = (N + 63) / 64;              // 10 (Q/K) or 25 (V) values per lane, kept in registers
-    float val[IT];
+    constexpr int IT = (N + 63) / 64;              // 10 (Q/K) or 25 (V) slots per lane
+    auto at = [&](int k) -> float {
+        const int i = lane + 64 * k;
+        return i < N ? ys[(i / D) * yp + col0 + (i % D)] : 0.f;
+    };
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < IT; ++k) {
-        const int i = lane + 64 * k;
-        const int ic = i < N ? i : N - 1;
-        val[k] = ys[(ic / D) * yp + col0 + (ic % D)];
-        if (i < N) s += val[k];
-    }
+    for (int k = 0; k < IT; ++k) s += at(k);
     const float mean = wave_sum(s) * (1.0f / N);
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < IT; ++k) {
-        const float dv = val[k] - mean;
+        const float dv = at(k) - mean;
         if (lane + 64 * k < N) v += dv * dv;
     }
     const float rstd = rsqrtf(wave_sum(v) * (1.0f / N) + LN_EPS);
 #pragma unroll
-    for (int k = 0; k < IT; ++k) {                 // fully unrolled: the affine loads of all slots are in flight together
+    for (int k = 0; k < IT; ++k) {
         const int i = lane + 64 * k;
-        const int ic = i < N ? i : N - 1;
-        const float o = (val[k] - mean) * rstd * gw[ic] + gb[ic];
-        if (i < ld) dst[i] = i < N ? o : 0.f;      // pad columns (q/kx) stay 0
+        if (i < N) dst[i] = (at(k) - mean) * rstd * gw[i] + gb[i];
+        else if (i < ld) dst[i] = 0.f;             // pad columns (q/kx) stay 0
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // Q/K/V projection + PReLU + per-head LayerNorm over (f,e); persistent workgroups, grid-stride over frames
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_qkv_proj_ln(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
+__global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slopes,
                                                      const float* __restrict__ lnq_w, const float* __restrict__ lnq_b,
                                                      const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(256) k_qkv_proj_ln(const float* __restrict__ y
         __syncthreads();                      // image complete; also orders the previous frame's reads of `ys`
         if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
-#pragma unroll
+#pragma unroll 1
         for (int m = 0; m < FR_RP / 16; ++m) {
             const f32x4 r0 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh0, wl0, bz0);
 #pragma unroll
@@ -256,16 +258,19 @@ __global__ void __launch_bounds__(256) k_qkv_proj_ln(const float* __restrict__ y
         // per-head LayerNorm: wave w normalises head w of Q, K and V; flat index = f*D + e (F-major, e-minor)
         const int hd = wave;
         const long bh = (long)b * NH + hd;
-        ln_head<E>(ys, YP, hd * E, lnq_w, lnq_b, q + (bh * T + t) * LDQK, LDQK, lane);
-        ln_head<E>(ys, YP, NH * E + hd * E, lnk_w, lnk_b, kx + (bh * (T + HIST) + HIST + t) * LDQK, LDQK, lane);
-        ln_head<VD>(ys, YP, 2 * NH * E + hd * VD, lnv_w, lnv_b, vx + (bh * (T + HIST) + HIST + t) * DV, DV, lane);
+        // `fr >> 30` is always 0 but ties the lane index to the loop variable: without it LICM hoists ~45 slot
+        // addresses per head out of the persistent frame loop and the kernel spills
+        const int ln = lane + (fr >> 30);
+        ln_head<E>(ys, YP, hd * E, lnq_w, lnq_b, q + (bh * T + t) * LDQK, LDQK, ln);
+        ln_head<E>(ys, YP, NH * E + hd * E, lnk_w, lnk_b, kx + (bh * (T + HIST) + HIST + t) * LDQK, LDQK, ln);
+        ln_head<VD>(ys, YP, 2 * NH * E + hd * VD, lnv_w, lnv_b, vx + (bh * (T + HIST) + HIST + t) * DV, DV, ln);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // attn_concat_proj + LN over (f,c) + residual (+ speaker gain); persistent, grid-stride over frames
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_proj_ln_res(const float* __restrict__ merged, const _Float16* __restrict__ w_pk,
+__global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict__ merged, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slope,
                                                      const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                      const float* __restrict__ y2, const float* __restrict__ gain,
@@ -308,7 +313,7 @@ __global__ void __launch_bounds__(256) k_proj_ln_res(const float* __restrict__ m
         for (int k = 0; k < NSLOT; ++k)
             rv[k] = *reinterpret_cast<const float4*>(&y2[fr + (long)min(tid + 256 * k, N4 - 1) * 4]);
 
-#pragma unroll
+#pragma unroll 1
         for (int m = 0; m < FR_RP / 16; ++m) {
             const f32x4 acc = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh, wl, bz);
 #pragma unroll

@@ -279,20 +279,20 @@ class Net(nn.Module):
             if self.gemm_mode not in ("f32", "f16x3"):
                 raise ValueError(f"gemm_mode must be 'f32' or 'f16x3', got {self.gemm_mode!r}")
             mode = 1 if self.gemm_mode == "f16x3" else 0
-            wkey = "_w16" if mode else "_w"
+            wkey, bkey = ("_w16", "_b16") if mode else ("_w", "_b")
             for i in range(self.n_blocks):
                 bp = pk["blocks"][i]
                 bs = state["gridnet_bufs"][f"buf{i}"]
                 # intra: LN + BiLSTM over frequency -> Linear(128->64) + residual
                 lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra" + wkey]),
-                         P(bp["intra_b"]), P(hbuf), Bn * T, mode, st)
+                         P(bp["intra" + bkey]), P(hbuf), Bn * T, mode, st)
                 lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
                          2 * H_, st)
                 # inter: LN + causal LSTM over time with carried state -> Linear(64->64) + residual
                 h0, c0 = c32(bs["h0"]), c32(bs["c0"])
                 hN, cN = new(h0), new(c0)
                 lib.call("lh_ln_lstm_inter", P(xb), P(bp["inter_ln_w"]), P(bp["inter_ln_b"]), P(bp["inter" + wkey]),
-                         P(bp["inter_b"]), P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, mode, st)
+                         P(bp["inter" + bkey]), P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, mode, st)
                 lib.call("lh_linear_res", P(hbuf), P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(xb), P(xc), rows,
                          H_, st)
                 # attention: history rows in, Q/K/V, local attention (head merge fused), projection + LN + residual

@@ -92,10 +92,20 @@ def pack_block(sd: dict, pre: str) -> dict:
     out["intra_ln_w"], out["intra_ln_b"] = g("intra_norm.norm.weight"), g("intra_norm.norm.bias")
     out["intra_w"] = torch.stack([pack_lstm(g("intra_rnn.weight_ih_l0"), g("intra_rnn.weight_hh_l0")),
                                   pack_lstm(g("intra_rnn.weight_ih_l0_reverse"), g("intra_rnn.weight_hh_l0_reverse"))])
-    out["intra_w16"] = torch.stack([pack_lstm_f16x3(g("intra_rnn.weight_ih_l0"), g("intra_rnn.weight_hh_l0")),
-                                    pack_lstm_f16x3(g("intra_rnn.weight_ih_l0_reverse"),
-                                                    g("intra_rnn.weight_hh_l0_reverse"))])
-    out["inter_w16"] = pack_lstm_f16x3(g("inter_rnn.weight_ih_l0"), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
+    # split-precision images with the LayerNorm affine folded in:  LN(x) W^T = xhat (W * ln_w)^T + W ln_b
+    iw, ib = g("intra_norm.norm.weight").double(), g("intra_norm.norm.bias").double()
+    ew, eb = g("inter_norm.norm.weight").double(), g("inter_norm.norm.bias").double()
+    fold_w = lambda w, lw: (w.double() * lw[None, :]).float()
+    fold_b = lambda w, lb, b1, b2: (b1.double() + b2.double() + w.double() @ lb).float()
+    out["intra_w16"] = torch.stack([
+        pack_lstm_f16x3(fold_w(g("intra_rnn.weight_ih_l0"), iw), g("intra_rnn.weight_hh_l0")),
+        pack_lstm_f16x3(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw), g("intra_rnn.weight_hh_l0_reverse"))])
+    out["intra_b16"] = torch.stack([
+        fold_b(g("intra_rnn.weight_ih_l0"), ib, g("intra_rnn.bias_ih_l0"), g("intra_rnn.bias_hh_l0")),
+        fold_b(g("intra_rnn.weight_ih_l0_reverse"), ib, g("intra_rnn.bias_ih_l0_reverse"),
+               g("intra_rnn.bias_hh_l0_reverse"))])
+    out["inter_w16"] = pack_lstm_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
+    out["inter_b16"] = fold_b(g("inter_rnn.weight_ih_l0"), eb, g("inter_rnn.bias_ih_l0"), g("inter_rnn.bias_hh_l0"))
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
     out["intra_lin_w"], out["intra_lin_b"] = pack_linear_f16x3(g("intra_linear.weight")), g("intra_linear.bias")

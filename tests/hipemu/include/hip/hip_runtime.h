@@ -317,6 +317,14 @@ template <class T> static inline T __shfl_up(T v, int d, int width = 64) {
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu::mfma_16x16x32_f16((a), (b), (c))
+// DPP row_ror:N (dpp_ctrl 0x121..0x12F): lane i of each 16-lane row reads lane (i - N) mod 16 of its row
+static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if (ctrl < 0x121 || ctrl > 0x12F || row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "hipemu: unsupported DPP ctrl %x\n", ctrl); abort(); }
+    int l = hipemu::lane_id();
+    int n = ctrl - 0x120;
+    return hipemu::shfl_any(src, (l & ~15) | (((l & 15) - n) & 15));
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
