@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
     const int g4 = lane >> 4, l15 = lane & 15;
 
     auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
-    auto step_pos = [&](int it) -> int { return dir ? (nstep - 1 - it) : it; };
+    // clamped: fetches/stores past either end of the sequence hit an in-range row and are harmless
+    auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
 
     // resident weights: hi/lo fp16 B fragments, [gate][kstep]; image = [dir][wave][gate][ks][lane][hi8|lo8]
     f16x8 wh[4][4], wl[4][4];
@@ -280,18 +281,20 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int rl = (tid + 256 * i) >> 4;
-            const int s = s0 + rl;
-            if (s < nseq)
-                *reinterpret_cast<float4*>(&h_out[row_of(s, p) * ldh + dir * H + q * 4]) =
-                    *reinterpret_cast<const float4*>(&hf[(buf * NS + rl) * LH_HP + q * 4]);
+            // tail rows (s >= nseq) are exact replicas of sequence nseq-1 (all their inputs are clamped), so the
+            // clamped, unconditional store rewrites identical bytes and the step body stays branch-free
+            const int s = min(s0 + rl, nseq - 1);
+            *reinterpret_cast<float4*>(&h_out[row_of(s, p) * ldh + dir * H + q * 4]) =
+                *reinterpret_cast<const float4*>(&hf[(buf * NS + rl) * LH_HP + q * 4]);
         }
     };
 
     float creg[MT][4];
+    float4 xr[MT];
     {
-        float4 xr[MT];
         load_x(0, xr);
         norm_store_x(0, xr);
+        load_x(1, xr);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int rl = (tid + 256 * i) >> 4;
@@ -299,6 +302,7 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
             store_split4(0, rl, C + q * 4, hv.x, hv.y, hv.z, hv.w);
+            *reinterpret_cast<float4*>(&hf[rl * LH_HP + q * 4]) = hv;
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -312,10 +316,13 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
 
     for (int it = 0; it < nstep; ++it) {
         const int cur = it & 1, nxt = cur ^ 1;
-        float4 xr[MT];
-        const bool more = (it + 1 < nstep);
-        if (more) load_x(it + 1, xr);
-        if (it > 0) flush_h(cur, it - 1);
+        // One straight-line block per step (no data-dependent branches) so the scheduler can slide the row-wise
+        // VALU work under the MFMAs: x_{t+1} (fetched a step ago) is normalised into the free buffer first,
+        // x_{t+2} is fetched, h_{t-1} is flushed (at t = 0 the initial state goes to the row of step 0, which
+        // the real h_0 overwrites one step later from the same thread).
+        norm_store_x(nxt, xr);
+        load_x(it + 2, xr);
+        flush_h(cur, it - 1);
 
         f32x4 accm[MT][4], accc[MT][4];
 #pragma unroll
@@ -361,7 +368,6 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
                 alo[(nxt * NS + rl) * LH_AP + C + unit] = tl;
                 hf[(nxt * NS + rl) * LH_HP + unit] = hv;
             }
-        if (more) norm_store_x(nxt, xr);
         __syncthreads();
     }
 
@@ -612,7 +618,7 @@ static int launch_lstm(const float* x, const float* lnw, const float* lnb, const
 }  // namespace lh
 
 namespace lh {
-static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [2] 1 = un-pipelined f16x3 kernel
+static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [2] 1 = software-pipelined f16x3 kernel (experimental, slower)
 }
 extern "C" int lh_set_tuning(int key, int value) {
     if (key < 0 || key >= 4) return LH_ERR_ARG;
@@ -627,7 +633,7 @@ extern "C" int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* 
     // sequence s = frame (b,t); step p = frequency bin; row(s,p) = s*97 + p
     const int mt = g_tune[0] ? g_tune[0] : (mode == LH_GEMM_F16X3 ? 1 : (n_frames >= 8192 ? 2 : 1));
     if (mode == LH_GEMM_F16X3) {
-        if (mt == 1 && g_tune[2] == 0)
+        if (mt == 1 && g_tune[2] == 1)
             return launch_lstm_p(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1,
                                  NF, 0, 1, 2 * H, (hipStream_t)stream);
         if (mt == 2)
@@ -656,7 +662,7 @@ extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* 
     const int nseq = B * NF;
     const int mt = g_tune[1] ? g_tune[1] : (nseq >= 32768 ? 2 : 1);
     if (mode == LH_GEMM_F16X3) {
-        if (mt == 1 && g_tune[2] == 0)
+        if (mt == 1 && g_tune[2] == 1)
             return launch_lstm_p(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
                                  (hipStream_t)stream);
         if (mt == 2)
