@@ -33,6 +33,8 @@ FLOPS_PER_CLIP = 46.67e9              # SURVEY.md §8(d) algorithmic FLOPs
 BYTES_PER_CLIP = 614.3e6              # SURVEY.md §8(d) algorithmic bytes (fp32, five fused stages per block)
 WEIGHT_BYTES = 8.15e6
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak (the f16x3 mode executes 3 fp16
+                                      # MFMAs per algorithmic fp32 product, so frac <= 1/3 by construction)
 PEAK_HBM_GBS = 8000.0
 
 # algorithmic work per LAUNCH and per clip of each kernel (FLOPs, bytes) — SURVEY.md §8(a)/(d), DESIGN.md §4
@@ -181,14 +183,23 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         dom = max(kern, key=lambda k: kern[k]["total_ms"])
         w = KERNEL_WORK[dom]
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from the PMC passes
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            if tj.get("batch_per_gpu") == B and dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
         if w["bound"] == "mfma":
             ach = w["flops"] * B / (kern[dom]["avg_ms"] * 1e-3) / 1e12
-            roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None)
+            peak = PEAK_F16_MFMA_TFLOPS if net.gemm_mode == "f16x3" else PEAK_FP32_MFMA_TFLOPS
+            roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
+                        traffic=traffic,
+                        note=("algorithmic fp32-equivalent FLOPs; f16x3 mode executes 3x as many fp16 MFMA FLOPs, "
+                              "peak = dense fp16 MFMA") if net.gemm_mode == "f16x3" else "exact fp32 MFMA")
         else:
             ach = w["bytes"] * B / (kern[dom]["avg_ms"] * 1e-3) / 1e9
             roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=ach / PEAK_HBM_GBS, traffic=None)
+                        frac=ach / PEAK_HBM_GBS, traffic=traffic)
         roof["avg_launch_ms"] = kern[dom]["avg_ms"]
         roof["share_of_gpu_time"] = kern[dom]["total_ms"] / gpu_ms
         out = {
