@@ -89,6 +89,41 @@ def cpu_baseline_subprocess(timeout_s=240):
         return dict(value=None, unit="frames/s", cores=0, kind="port", sample=f"timed out after {timeout_s} s")
 
 
+def bench_stream(args, net, dev, rank, world):
+    """BASELINE configs[1]: batch-1 (or --batch N independent streams) chunked forward, hop 128, 64-sample look-ahead.
+    A step = one 8 ms chunk through the graph-captured per-chunk launch sequence; replicas only across GPUs."""
+    from lookoncetohear_amd import synth
+    B = 1 if args.batch == 32 else args.batch
+    d = synth.batch(list(range(B)), 80000)
+    mix = torch.nn.functional.pad(d["mixture"], (0, 64)).to(dev)
+    st = net.make_streamer(B, dev, use_graph=True)
+    st.set_embedding(d["embedding_gt"].to(dev))
+    nchunks = 625
+    chunks = [mix[:, :, i * 128:i * 128 + 192].contiguous() for i in range(nchunks)]
+    for i in range(args.warmup):
+        st.step(chunks[i % nchunks])
+    torch.cuda.synchronize()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        t1 = time.perf_counter()
+        y = st.step(chunks[i % nchunks])
+        torch.cuda.synchronize()                 # a real-time consumer needs the chunk before the next one arrives
+        lat.append(time.perf_counter() - t1)
+    elapsed = time.perf_counter() - t0
+    lat.sort()
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({
+            "metric": "streaming chunk latency / real-time factor (128-sample hop, 64-sample look-ahead)",
+            "value": B * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "replicas",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf": ms / 8.0,
+            "latency_ms": {"p50": lat[len(lat) // 2] * 1e3, "p99": lat[int(len(lat) * 0.99)] * 1e3, "max": lat[-1] * 1e3},
+            "config": {"workload": f"BASELINE configs[1]: {B} stream(s), 8 ms chunks with carried state, HIP-graph replay",
+                       "batch_per_gpu": B, "gemm_mode": net.gemm_mode}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +131,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE configs[2] = 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="offline", choices=["offline", "stream"],
+                    help="offline = BASELINE configs[2] (default, the headline line); stream = configs[1]: 8 ms chunks, "
+                         "carried state, HIP-graph replay per chunk (a step = one chunk)")
     ap.add_argument("--gemm", default=None, choices=["f32", "f16x3"], help="override Net.gemm_mode (A/B runs)")
     ap.add_argument("--tune", default="", help="comma list key=value for lh_set_tuning (A/B runs), e.g. 0=2,1=1")
     args = ap.parse_args()
@@ -127,6 +165,9 @@ def main():
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         assert _cabi.load().raw("lh_set_tuning")(int(k), int(v)) == 0
+
+    if args.mode == "stream":
+        return bench_stream(args, net, dev, rank, world)
 
     B = args.batch
     # utterance sharding: rank r owns utterances r*B .. r*B+B-1 (seeded by index -> rank-count invariant union);

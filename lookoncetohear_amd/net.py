@@ -187,6 +187,10 @@ class Net(nn.Module):
         x, next_state = self.predict(x, embeds, input_state, pad)
         return x
 
+    def make_streamer(self, batch_size: int, device, use_graph: bool = True):
+        """Chunked real-time front end (BASELINE configs[1]): see `Streamer`."""
+        return Streamer(self, batch_size, device, use_graph)
+
     # ------------------------------------------------------------------------------------------------
     # host-side plumbing
     # ------------------------------------------------------------------------------------------------
@@ -323,3 +327,84 @@ class Net(nn.Module):
                      P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), Bn, T, st)
             state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
         return y, state
+
+
+class Streamer:
+    """8 ms-chunk streaming driver (reference usage: `Net.predict(chunk[B,2,192], embed[B,256], state, pad=False)`
+    in a loop) with the per-chunk launch sequence captured once into a HIP graph.
+
+    One chunk = 128 new samples + 64 look-ahead samples -> 128 output samples; all streaming state (conv / deconv /
+    iSTFT tails, LSTM (h, c), K/V rings) lives in static device tensors that the captured graph reads and rewrites,
+    so `step()` is: copy the chunk in, replay the graph, hand back the output buffer (a view that the next `step`
+    overwrites).  `use_graph=False` runs the same code path eagerly (also what the capture warm-up does).
+    """
+
+    def __init__(self, net: Net, batch_size: int, device, use_graph: bool = True):
+        self.net = net
+        self.B = batch_size
+        self.device = torch.device(device)
+        n = net.stft_chunk_size + net.stft_pad_size
+        self.chunk = torch.zeros(batch_size, net.num_ch, n, device=self.device)
+        self.embed = torch.zeros(batch_size, net.spk_emb_dim, device=self.device)
+        self.state = net.init_buffers(batch_size, self.device)
+        self.out = torch.zeros(batch_size, net.n_srcs, net.stft_chunk_size, device=self.device)
+        self.graph = None
+        if use_graph and self.device.type == "cuda":
+            saved = self._snapshot()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):              # warm-up: packs weights, allocates the T=1 workspace
+                    self._body()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body()
+            self.graph = g
+            self._restore(saved)
+
+    def _flat(self):
+        st = self.state
+        out = [st["conv_buf"], st["deconv_buf"], st["istft_buf"]]
+        for i in range(self.net.n_blocks):
+            b = st["gridnet_bufs"][f"buf{i}"]
+            out += [b["K_buf"], b["V_buf"], b["c0"], b["h0"]]
+        return out
+
+    def _snapshot(self):
+        return [t.clone() for t in self._flat()]
+
+    def _restore(self, saved):
+        for t, s in zip(self._flat(), saved):
+            t.copy_(s)
+
+    def _body(self):
+        old = self._flat()
+        work = dict(conv_buf=old[0], deconv_buf=old[1], istft_buf=old[2], gridnet_bufs={
+            f"buf{i}": dict(K_buf=old[3 + 4 * i], V_buf=old[4 + 4 * i], c0=old[5 + 4 * i], h0=old[6 + 4 * i])
+            for i in range(self.net.n_blocks)})
+        y, new = self.net.predict(self.chunk, self.embed, work, pad=False)
+        self.out.copy_(y)
+        flat_new = [new["conv_buf"], new["deconv_buf"], new["istft_buf"]]
+        for i in range(self.net.n_blocks):
+            b = new["gridnet_bufs"][f"buf{i}"]
+            flat_new += [b["K_buf"], b["V_buf"], b["c0"], b["h0"]]
+        for dst, src in zip(old, flat_new):     # write the new state back into the static tensors
+            dst.copy_(src)
+
+    def reset(self):
+        for t in self._flat():
+            t.zero_()
+
+    def set_embedding(self, embed: torch.Tensor):
+        self.embed.copy_(embed.reshape(self.B, -1))
+
+    def step(self, chunk: torch.Tensor) -> torch.Tensor:
+        """chunk [B, 2, 192] (128 new + 64 look-ahead samples) -> [B, 2, 128]."""
+        self.chunk.copy_(chunk)
+        with torch.no_grad():
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._body()
+        return self.out
