@@ -207,7 +207,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 }
 
 template <int MT>
-__global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const float* __restrict__ x, const float* __restrict__ lnw,
+__global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__ x, const float* __restrict__ lnw,
                                                     const float* __restrict__ lnb, const _Float16* __restrict__ w_pk,
                                                     const float* __restrict__ b_sum, const float* __restrict__ h0,
                                                     const float* __restrict__ c0, float* __restrict__ hN,
@@ -324,40 +324,44 @@ __global__ void __launch_bounds__(256, (MT == 1 ? 2 : 1)) k_ln_lstm_h3(const flo
         load_x(it + 2, xr);
         flush_h(cur, it - 1);
 
-        f32x4 accm[MT][4], accc[MT][4];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                accm[m][g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
-                accc[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        // Per 16-sequence tile: 48 MFMAs, then the two split accumulators collapse to 16 gate pre-activations so
+        // the accumulator registers are free again; with MT = 2 the second tile's MFMAs have no dependence on the
+        // first tile's cell update and the scheduler overlaps matrix and VALU work inside the wave.
+        constexpr float INV = 1.0f / SPLIT_SCALE;
+        f32x4 gate[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            f32x4 accm[4], accc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                accm[g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
+                accc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             const int ro = (cur * NS + m * 16 + l15) * LH_AP + g4 * 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) accm[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], accm[m][g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) accm[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], accm[g], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) accc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], accc[m][g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], accc[g], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) accc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], accc[m][g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], accc[g], 0, 0, 0);
             }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gate[m][g] = accm[g] + accc[g] * INV;
         }
 
         const int unit = wave * 16 + l15;
-        constexpr float INV = 1.0f / SPLIT_SCALE;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float ig = sigmoid_f(accm[m][0][r] + accc[m][0][r] * INV);
-                const float fg = sigmoid_f(accm[m][1][r] + accc[m][1][r] * INV);
-                const float gg = tanh_f(accm[m][2][r] + accc[m][2][r] * INV);
-                const float og = sigmoid_f(accm[m][3][r] + accc[m][3][r] * INV);
+                const float ig = sigmoid_f(gate[m][0][r]);
+                const float fg = sigmoid_f(gate[m][1][r]);
+                const float gg = tanh_f(gate[m][2][r]);
+                const float og = sigmoid_f(gate[m][3][r]);
                 const float cc = fg * creg[m][r] + ig * gg;
                 creg[m][r] = cc;
                 const float hv = og * tanh_f(cc);
