@@ -55,8 +55,9 @@ int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unu
  * Replaces tfgridnet_causal.py:229-242 (asteroid Encoder conv1d, cat/transpose, conv_buf halo, self.conv).
  *   x            [B][2][n_samples]                 n_samples = 128*T + 64
  *   conv_buf_in  [B][4][2][97]   conv_buf_out same shape (last two frames of the halo-extended spectrum)
- *   wfb_t        [192][194]      enc.filterbank._filters transposed (n-major)
- *   wconv_pk     [36][64]        conv.0.weight as [(ch*3+kt)*3+kf][o];  bconv [64]
+ *   wfb_t        fp32 MFMA B image [13 tiles][48 ksteps][64 lanes] of enc.filterbank._filters^T [192 x 194]
+ *   wconv_pk     fp32 MFMA B image [4 tiles][9 ksteps][64 lanes] of conv.0.weight as [36 taps (ch,kt,kf)] x [64]
+ *                (weights.py pack_mfma_f32);  bconv [64]
  *   z            [B][T][97][64]  out
  */
 int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* conv_buf_out, const float* wfb_t,
@@ -135,7 +136,8 @@ int lh_proj_ln_res(const float* merged, const void* w_pk, const float* bias, con
 /* A.4  causal ConvTranspose2d(64->4,3x3) + spectrum re-pack + iSTFT synthesis/overlap-add.
  * Replaces tfgridnet_causal.py:256-273 and the look-ahead trim of net.py:61.
  *   y [B][T][97][64]; deconv_buf_in/out [B][64][2][97]; istft_buf_in/out [B][2][194][1]
- *   wdec_pk [4][3][3][64] deconv.weight as [o][kt][kf][c]; bdec [4]; wfb_dec [194][192]
+ *   wdec_pk fp32 MFMA B image [3 tiles][16 ksteps][64 lanes] of deconv.weight as [64 c] x [(kt,kf,o) 36 -> 48];
+ *   bdec [4]; wfb_dec fp32 MFMA B image [12 tiles][52 ksteps][64 lanes] of dec.filterbank._filters [194 -> 208 x 192]
  *   wave_out [B][2][128*T]
  */
 int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out, const float* istft_buf_in,

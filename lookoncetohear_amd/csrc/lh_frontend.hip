@@ -5,95 +5,150 @@
 
 namespace lh {
 
-constexpr int FE_TT = 8;                       // frames per workgroup
-constexpr int FE_NJ = FE_TT + 2;               // + 2 halo frames of the causal conv
-constexpr int FE_NS = FE_NJ * HOP + (NFFT - HOP);   // samples staged per mic
+// ---- STFT analysis + causal 3x3 conv on fp32 MFMA (exact fp32), persistent workgroups --------------------------
+// A tile = 14 output frames of one utterance (+2 halo frames of the causal conv = 16 STFT frames = one MFMA row
+// tile per microphone).  The analysis filterbank lives in VGPRs for the whole kernel as B fragments (wave w owns
+// filter-row tiles w, w+4, w+8(, 12): 144-192 registers), frames are staged once in LDS as the A image, the
+// spectrum tile [4 ch][16 frames][97 bins] stays in LDS, and the conv is a [97 x 36] x [36 x 64] MFMA contraction
+// per frame whose A operand is gathered straight from the spectrum tile; output rows leave through LDS as
+// 256-byte coalesced stores.
+constexpr int FE_TT = 14;                      // output frames per tile
+constexpr int FE_NJ = 16;                      // STFT frames per tile (2 halo + 14)
+constexpr int FE_KC = NFFT / 4;                // 48: k-chunk of one 16-lane group
+constexpr int FE_KP = FE_KC + 4;               // 52: padded chunk row (13 x 16 B: conflict-free ds_read_b128)
 constexpr int FE_SROW = NF + 3;                // spectrum row: [0]=0 pad, [1..97]=bins, [98]=0 pad, [99] unused
+constexpr int FE_NT = (NK + 15) / 16;          // 13 filter-row tiles (194 -> 208)
+constexpr int FE_OP = C + 4;                   // output staging row
 
-// grid (ceil(T/8), B), block 256
-__global__ void __launch_bounds__(256) k_stft_conv_in(const float* __restrict__ x, const float* __restrict__ cbuf_in,
-                                                       float* __restrict__ cbuf_out, const float* __restrict__ wfb_t,
-                                                       const float* __restrict__ wc_pk, const float* __restrict__ bc,
-                                                       float* __restrict__ z, int T, int n_samples) {
-    __shared__ float xs[NMIC][FE_NS];
+__global__ void __launch_bounds__(256, 1) k_stft_conv_in(const float* __restrict__ x, const float* __restrict__ cbuf_in,
+                                                          float* __restrict__ cbuf_out, const float* __restrict__ wfb_pk,
+                                                          const float* __restrict__ wc_pk, const float* __restrict__ bc,
+                                                          float* __restrict__ z, int B, int T, int n_samples) {
+    __shared__ __attribute__((aligned(16))) float aimg[NMIC * 4 * FE_NJ * FE_KP];
     __shared__ float spec[2 * NMIC][FE_NJ][FE_SROW];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * FE_TT;
-    const int nt = min(FE_TT, T - t0);
+    __shared__ __attribute__((aligned(16))) float outs[NF * FE_OP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
-    // stage samples of frames t0-2 .. t0+TT-1 (zeros outside the signal)
-    const long sb = (long)(t0 - 2) * HOP;
-    for (int i = tid; i < NMIC * FE_NS; i += 256) {
-        int m = i / FE_NS, s = i % FE_NS;
-        long g = sb + s;
-        xs[m][s] = (g >= 0 && g < n_samples) ? x[((long)b * NMIC + m) * n_samples + g] : 0.0f;
+    // resident B fragments: filterbank tiles of this wave, conv weights of its 16 output channels
+    float wf[4][FE_KC];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nt = min(wave + 4 * i, FE_NT - 1);
+#pragma unroll
+        for (int ks = 0; ks < FE_KC; ++ks) wf[i][ks] = wfb_pk[((long)nt * FE_KC + ks) * 64 + lane];
     }
-    for (int i = tid; i < 2 * NMIC * FE_NJ; i += 256) {
+    float wcv[9];
+    int aoff[9];                               // spectrum-tile offset of conv tap q = g4*9 + ks -> (ch, kt, kf)
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
+        wcv[ks] = wc_pk[(wave * 9 + ks) * 64 + lane];
+        const int qq = g4 * 9 + ks, ch = qq / 9, kt = (qq % 9) / 3, kf = qq % 3;
+        aoff[ks] = (ch * FE_NJ + kt) * FE_SROW + kf;
+    }
+    const float cbias = bc[wave * 16 + l15];
+
+    for (int i = tid; i < 2 * NMIC * FE_NJ; i += 256) {        // zero the frequency padding columns once
         float* row = &spec[0][0][0] + i * FE_SROW;
         row[0] = 0.0f; row[NF + 1] = 0.0f; row[NF + 2] = 0.0f;
     }
-    __syncthreads();
 
-    // spectrum: thread k owns filter row k (k<97 real part of bin k, k>=97 imaginary part of bin k-97)
-    if (tid < NK) {
-        const int k = tid;
-        float acc[NMIC][FE_NJ];
+    const int tiles_per_b = (T + FE_TT - 1) / FE_TT;
+    for (int tile = blockIdx.x; tile < B * tiles_per_b; tile += gridDim.x) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile % tiles_per_b) * FE_TT;
+        const int nt_out = min(FE_TT, T - t0);
+        __syncthreads();                       // previous tile fully consumed (aimg / spec / outs)
+
+        // stage the 16 frames of both microphones: frame j = samples (t0-2+j)*128 .. +192, 48 float4 each
+        {
+            float4 stg[6];
 #pragma unroll
-        for (int m = 0; m < NMIC; ++m)
-#pragma unroll
-            for (int j = 0; j < FE_NJ; ++j) acc[m][j] = 0.0f;
-#pragma unroll 8
-        for (int n = 0; n < NFFT; ++n) {
-            const float w = wfb_t[n * NK + k];
-#pragma unroll
-            for (int m = 0; m < NMIC; ++m)
-#pragma unroll
-                for (int j = 0; j < FE_NJ; ++j) acc[m][j] = fmaf(xs[m][j * HOP + n], w, acc[m][j]);
-        }
-        const int f = k % NF;
-        const int part = k / NF;                      // 0 = re, 1 = im
-#pragma unroll
-        for (int m = 0; m < NMIC; ++m) {
-            const int ch = part * NMIC + m;           // channel order re_m0, re_m1, im_m0, im_m1
-#pragma unroll
-            for (int j = 0; j < FE_NJ; ++j) {
+            for (int i = 0; i < 6; ++i) {
+                const int e = tid + 256 * i;
+                const int m = e / (FE_NJ * 48), j = (e / 48) % FE_NJ, c4 = e % 48;
                 const int t = t0 - 2 + j;
-                float v = acc[m][j];
-                if (t < 0) v = cbuf_in[(((long)b * 4 + ch) * 2 + (t + 2)) * NF + f];   // carried halo frames
-                if (t >= T) v = 0.0f;
-                spec[ch][j][1 + f] = v;
+                stg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t >= 0 && t < T)
+                    stg[i] = *reinterpret_cast<const float4*>(&x[((long)b * NMIC + m) * n_samples + (long)t * HOP + c4 * 4]);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int e = tid + 256 * i;
+                const int m = e / (FE_NJ * 48), j = (e / 48) % FE_NJ, c4 = e % 48;
+                *reinterpret_cast<float4*>(&aimg[((m * 4 + c4 / 12) * FE_NJ + j) * FE_KP + (c4 % 12) * 4]) = stg[i];
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // new halo state = last two frames of the halo-extended spectrum (only the last tile holds them)
-    if (t0 + nt == T) {
-        for (int i = tid; i < 4 * 2 * NF; i += 256) {
-            int f = i % NF, r = (i / NF) % 2, ch = i / (2 * NF);
-            int j = (T - 2 + r) - t0 + 2;
-            cbuf_out[(((long)b * 4 + ch) * 2 + r) * NF + f] = spec[ch][j][1 + f];
+        // spectrum: [16 frames x 192] x [192 x 16 filter rows] per (mic, tile)
+#pragma unroll
+        for (int m = 0; m < NMIC; ++m) {
+            float av[FE_KC];
+            const float* arow = &aimg[((m * 4 + g4) * FE_NJ + l15) * FE_KP];
+#pragma unroll
+            for (int qq = 0; qq < FE_KC / 4; ++qq) {
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
+                av[qq * 4 + 0] = a4.x; av[qq * 4 + 1] = a4.y; av[qq * 4 + 2] = a4.z; av[qq * 4 + 3] = a4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nt = wave + 4 * i;
+                if (nt < FE_NT) {              // wave-uniform
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < FE_KC; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wf[i][ks], acc, 0, 0, 0);
+                    const int k = nt * 16 + l15;                       // filter row: k < 97 re, 97..193 im
+                    if (k < NK) {
+                        const int ch = (k / NF) * NMIC + m, f = k % NF;    // channels re_m0, re_m1, im_m0, im_m1
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = g4 * 4 + r, t = t0 - 2 + j;
+                            float v = acc[r];
+                            if (t < 0) v = cbuf_in[(((long)b * 4 + ch) * 2 + (t + 2)) * NF + f];   // carried halo frames
+                            if (t >= T) v = 0.0f;
+                            spec[ch][j][1 + f] = v;
+                        }
+                    }
+                }
+            }
         }
-    }
+        __syncthreads();
 
-    // 3x3 conv, 4 -> 64 channels: lane = output channel, the 4 waves stride over (frame, bin) positions
-    const int o = tid & 63;
-    const int grp = tid >> 6;
-    float w[36];
+        // new halo state = last two frames of the halo-extended spectrum (only the last tile holds them)
+        if (t0 + nt_out == T) {
+            for (int i = tid; i < 4 * 2 * NF; i += 256) {
+                const int f = i % NF, r = (i / NF) % 2, ch = i / (2 * NF);
+                cbuf_out[(((long)b * 4 + ch) * 2 + r) * NF + f] = spec[ch][(T - 2 + r) - t0 + 2][1 + f];
+            }
+        }
+
+        // conv: per output frame [97 bins x 36 taps] x [36 x 16 channels of this wave]; A gathered from the tile
+        for (int jt = 0; jt < nt_out; ++jt) {
+            f32x4 acc[7];
 #pragma unroll
-    for (int q = 0; q < 36; ++q) w[q] = wc_pk[q * C + o];
-    const float bias = bc[o];
-    for (int pos = grp; pos < nt * NF; pos += 4) {
-        const int jt = pos / NF, f = pos % NF;
-        float a = bias;
+            for (int mt = 0; mt < 7; ++mt) acc[mt] = f32x4{cbias, cbias, cbias, cbias};
+            const float* sp = &spec[0][0][0] + jt * FE_SROW;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch)
+            for (int ks = 0; ks < 9; ++ks) {
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
+                for (int mt = 0; mt < 7; ++mt) {
+                    const int f = min(mt * 16 + l15, NF - 1);          // rows >= 97 are dropped below
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sp[aoff[ks] + f], wcv[ks], acc[mt], 0, 0, 0);
+                }
+            }
 #pragma unroll
-                for (int kf = 0; kf < 3; ++kf) a = fmaf(spec[ch][jt + kt][f + kf], w[(ch * 3 + kt) * 3 + kf], a);
-        z[(((long)b * T + t0 + jt) * NF + f) * C + o] = a;
+            for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = mt * 16 + g4 * 4 + r;
+                    if (f < NF) outs[f * FE_OP + wave * 16 + l15] = acc[mt][r];
+                }
+            __syncthreads();
+            float* dst = z + (((long)b * T + t0 + jt) * NF) * C;
+            for (int e = tid; e < NF * 16; e += 256)
+                *reinterpret_cast<float4*>(&dst[e * 4]) = *reinterpret_cast<const float4*>(&outs[(e >> 4) * FE_OP + (e & 15) * 4]);
+            __syncthreads();
+        }
     }
 }
 
@@ -154,8 +209,9 @@ extern "C" int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* 
     using namespace lh;
     if (!x || !conv_buf_in || !conv_buf_out || !wfb_t || !wconv_pk || !bconv || !z || B <= 0 || T <= 0) return LH_ERR_ARG;
     if (conv_buf_in == conv_buf_out || n_samples != T * HOP + (NFFT - HOP)) return LH_ERR_ARG;
-    hipLaunchKernelGGL(k_stft_conv_in, dim3((T + FE_TT - 1) / FE_TT, B), dim3(256), 0, (hipStream_t)stream, x,
-                       conv_buf_in, conv_buf_out, wfb_t, wconv_pk, bconv, z, T, n_samples);
+    const int tiles = B * ((T + FE_TT - 1) / FE_TT);
+    hipLaunchKernelGGL(k_stft_conv_in, dim3(tiles < 256 ? tiles : 256), dim3(256), 0, (hipStream_t)stream, x,
+                       conv_buf_in, conv_buf_out, wfb_t, wconv_pk, bconv, z, B, T, n_samples);
     return check_launch();
 }
 

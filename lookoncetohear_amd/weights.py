@@ -126,17 +126,32 @@ def pack_block(sd: dict, pre: str) -> dict:
     return {k: (v.contiguous() if v.dtype == torch.float16 else v.contiguous().float()) for k, v in out.items()}
 
 
+def pack_mfma_f32(w_kn: torch.Tensor, k_pad: int = None) -> torch.Tensor:
+    """fp32 MFMA (16x16x4) B image of a [K, N] matrix: [N/16 tiles][K/4 ksteps][64 lanes] with lane l of (nt, ks)
+    holding w_kn[k = (l >> 4) * (K/4) + ks][n = nt*16 + (l & 15)] (rows >= K / columns >= N are zero)."""
+    K0, N = w_kn.shape
+    K = k_pad or K0
+    assert K % 4 == 0 and K >= K0
+    n_pad = (N + 15) // 16 * 16
+    w = torch.zeros(K, n_pad, device=w_kn.device, dtype=torch.float32)
+    w[:K0, :N] = w_kn.float()
+    lane = torch.arange(64, device=w.device)
+    k = (lane >> 4)[None, None, :] * (K // 4) + torch.arange(K // 4, device=w.device)[None, :, None]
+    n = torch.arange(n_pad // 16, device=w.device)[:, None, None] * 16 + (lane & 15)[None, None, :]
+    return w[k, n].contiguous()
+
+
 def pack_all(sd: dict, n_blocks: int, prefix: str = "tfgridnet.") -> dict:
     """sd: state-dict-like mapping with the reference names -> dict of packed fp32 tensors."""
     g = lambda k: sd[prefix + k].detach()
     out = {
-        "wfb_t": g("enc.filterbank._filters")[:, 0].t(),                     # [192, 194]
-        "wfb_dec": g("dec.filterbank._filters")[:, 0],                       # [194, 192]
-        "conv_w": g("conv.0.weight").permute(1, 2, 3, 0).reshape(36, -1),    # [(ch,kt,kf), o]
+        "wfb_t": pack_mfma_f32(g("enc.filterbank._filters")[:, 0].t()),      # [192 samples, 194 rows] -> [13][48][64]
+        "wfb_dec": pack_mfma_f32(g("dec.filterbank._filters")[:, 0], k_pad=208),   # [194 -> 208, 192] -> [12][52][64]
+        "conv_w": pack_mfma_f32(g("conv.0.weight").reshape(-1, 36).t()),     # [36 taps (ch,kt,kf), 64] -> [4][9][64]
         "conv_b": g("conv.0.bias"),
         "emb_w": g("embed_to_feats_proj.0.weight"), "emb_b": g("embed_to_feats_proj.0.bias"),
         "emb_ln_w": g("embed_to_feats_proj.1.weight"), "emb_ln_b": g("embed_to_feats_proj.1.bias"),
-        "deconv_w": g("deconv.weight").permute(1, 2, 3, 0),                  # [o, kt, kf, c]
+        "deconv_w": pack_mfma_f32(g("deconv.weight").permute(0, 2, 3, 1).reshape(-1, 36)),   # [64, (kt,kf,o)] -> [3][16][64]
         "deconv_b": g("deconv.bias"),
     }
     out = {k: v.contiguous().float() for k, v in out.items()}
