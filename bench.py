@@ -152,7 +152,7 @@ def main():
 
     from lookoncetohear_amd import synth, _cabi
     from lookoncetohear_amd.net import Net
-    from lookoncetohear_amd.metrics import metric_sums
+    from lookoncetohear_amd.metrics import metric_sums_device
     from oracle import tfgridnet_oracle as O
     _cabi.load()                                                    # fail loudly if the HIP extension is missing
 
@@ -181,7 +181,7 @@ def main():
 
     def step():
         y = net(mix, emb)
-        sums = metric_sums(y, mix, tgt, emb[:, 0], emb[:, 0])       # [sum si_snr_i, sum out_sisnr, sum cos, n] fp64
+        sums, _ = metric_sums_device(y, mix, tgt, emb[:, 0], emb[:, 0])   # [sum si_snr_i, sum out_sisnr, sum cos, n] fp64
         if dist is not None:
             dist.all_reduce(sums)                                   # the path's only exchange step (32 B)
         return y, sums

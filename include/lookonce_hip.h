@@ -144,6 +144,17 @@ int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_bu
                     float* istft_buf_out, const float* wdec_pk, const float* bdec, const float* wfb_dec,
                     float* wave_out, int B, int T, lh_stream_t stream);
 
+/* Eval metrics on the device (reference src/ts_hear_test.py:139-146, torchmetrics SI-SNR restated): per utterance
+ * output_sisnr, si_snr_i (both averaged over the 2 channels) and cosine(embedding, embedding_gt); fp64 moments.
+ *   outputs, target, mixture [B][2][n_samples]; emb, emb_gt [B][emb_dim]
+ *   scratch  fp64 workspace, B*2*16*8 + B*3 doubles
+ *   rows     [B][3] fp32 = (output_sisnr, si_snr_i, embedding_sim)   (the CSV columns of ts_hear_test.py:149-151)
+ *   sums     [4] fp64 = (sum si_snr_i, sum output_sisnr, sum embedding_sim, B): the all-reduce payload
+ */
+int lh_metric_sums(const float* outputs, const float* target, const float* mixture, const float* emb,
+                   const float* emb_gt, double* scratch, float* rows, double* sums, int B, int n_samples,
+                   int emb_dim, lh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

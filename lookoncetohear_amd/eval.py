@@ -11,7 +11,7 @@ from typing import Callable, Iterable, List, Optional
 
 import torch
 
-from .metrics import metric_sums, per_utterance
+from .metrics import metric_sums, metric_sums_device, per_utterance
 
 
 def shard_indices(n_utts: int, rank: int, world: int) -> List[int]:
@@ -41,8 +41,13 @@ def evaluate(model: Callable, data_fn: Callable[[List[int]], dict], n_utts: int,
             else:
                 embedding = emb_gt                           # :137
             outputs = model(mixture, embedding)              # :138  <- the hot path
-            total += metric_sums(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
-            o, i, c = per_utterance(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
+            if outputs.is_cuda:                              # HIP metric kernels: no waveform leaves the device
+                sums, r = metric_sums_device(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
+                total += sums
+                o, i, c = r[:, 0], r[:, 1], r[:, 2]
+            else:                                            # host tensors (CPU tests of the sharding plumbing)
+                total += metric_sums(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
+                o, i, c = per_utterance(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
             rows += [dict(idx=k, output_sisnr=float(a), si_snr_i=float(b), embedding_sim=float(e))
                      for k, a, b, e in zip(idx, o.tolist(), i.tolist(), c.tolist())]
     if dist is not None and world > 1:

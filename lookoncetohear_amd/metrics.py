@@ -34,3 +34,25 @@ def metric_sums(outputs, mixture, target, embedding, embedding_gt) -> torch.Tens
     o, i, c = per_utterance(outputs, mixture, target, embedding, embedding_gt)
     n = torch.tensor(float(outputs.shape[0]), device=outputs.device, dtype=torch.float64)
     return torch.stack([i.double().sum(), o.double().sum(), c.double().sum(), n])
+
+
+def metric_sums_device(outputs, mixture, target, embedding, embedding_gt, lib=None):
+    """Same quantities through the HIP kernels of lh_metrics.hip (fp64 moments, one pass over the waveforms).
+    Returns (sums [4] fp64 on device, rows [B,3] fp32 = output_sisnr, si_snr_i, embedding_sim)."""
+    from . import _cabi
+    if lib is None:
+        if not outputs.is_cuda:
+            raise RuntimeError("metric_sums_device needs ROCm device tensors (use metric_sums for host tensors)")
+        lib = _cabi.load()
+    B, _, n = outputs.shape
+    dev = outputs.device
+    c32 = lambda t: t.contiguous().float()
+    o, m, t = c32(outputs), c32(mixture), c32(target)
+    e, g = c32(embedding.reshape(B, -1)), c32(embedding_gt.reshape(B, -1))
+    scratch = torch.empty(B * 2 * 16 * 8 + B * 3, dtype=torch.float64, device=dev)
+    rows = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    sums = torch.empty(4, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream if outputs.is_cuda else 0
+    lib.call("lh_metric_sums", o.data_ptr(), t.data_ptr(), m.data_ptr(), e.data_ptr(), g.data_ptr(), scratch.data_ptr(),
+             rows.data_ptr(), sums.data_ptr(), B, n, e.shape[1], st)
+    return sums, rows

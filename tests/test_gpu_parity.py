@@ -146,6 +146,20 @@ def test_graph_streamer_matches_eager(net, golden):
     assert torch.equal(ys, torch.cat(outs2, -1))
 
 
+def test_metric_kernels_match_torch_definition(net):
+    from lookoncetohear_amd.metrics import metric_sums, metric_sums_device, per_utterance
+    d = synth.batch([11, 12, 13], 80000)
+    g = torch.Generator().manual_seed(3)
+    out = 0.7 * d["target"] + 0.05 * torch.randn(d["target"].shape, generator=g) + 0.01
+    emb = d["embedding_gt"][:, 0]
+    e2 = emb + 0.05 * torch.randn(emb.shape, generator=g)
+    sums, rows = metric_sums_device(out.to(DEV), d["mixture"].to(DEV), d["target"].to(DEV), e2.to(DEV), emb.to(DEV))
+    ref = metric_sums(out.double(), d["mixture"].double(), d["target"].double(), e2.double(), emb.double())
+    assert torch.allclose(sums.cpu(), ref, rtol=1e-6, atol=1e-5)
+    o, i, c = per_utterance(out.double(), d["mixture"].double(), d["target"].double(), e2.double(), emb.double())
+    assert _err(rows, torch.stack([o, i, c], 1).float()) < 1e-4
+
+
 def test_edge_cases(net, oracle_cfg_sd):
     cfg, sd = oracle_cfg_sd
     for n in (1, 127, 128, 129, 2049):            # shorter than a hop, exact hop, ragged lengths
