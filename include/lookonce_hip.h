@@ -92,6 +92,23 @@ int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const
                      const float* h0, const float* c0, float* hN, float* cN, float* h_out, int B, int T, int mode,
                      lh_stream_t stream);
 
+/* A.3.1 + Linear fused (split-precision mode): LayerNorm -> BiLSTM over frequency -> Linear(128->64) -> + residual in
+ * ONE kernel; replaces tfgridnet_causal.py:505-516.  A workgroup runs the forward then the reverse direction over its
+ * sequences and accumulates both halves of the projection into the same output rows (no hidden-state round trip).
+ *   x, out [B*T][97][64] (must not alias); w_pk / b_sum as lh_ln_lstm_intra in LH_GEMM_F16X3 mode;
+ *   wlin_pk [2 passes][4 ntiles][2 ksteps][64 lanes][hi 8 | lo 8] = intra_linear.weight[:, 0:64] and [:, 64:128]
+ *   (weights.py pack_linear_f16x3); blin [64]
+ */
+int lh_intra_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                   float* out, int n_frames, lh_stream_t stream);
+
+/* A.3.2 + Linear fused: LayerNorm -> causal LSTM over time (state in/out) -> Linear(64->64) -> + residual;
+ * replaces tfgridnet_causal.py:521-538.   x, out [B][T][97][64]; wlin_pk [4][2][64][16] fp16 hi/lo; blin [64]
+ */
+int lh_inter_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                   const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,
+                   lh_stream_t stream);
+
 /* Row-wise Linear(K->64) + bias + residual:  out[r][:] = res[r][:] + W h[r][:] + b.
  * Replaces intra_linear + residual (tfgridnet_causal.py:513-516, K=128) and inter_linear + view/transpose +
  * residual (:534-538, K=64).   h [rows][K]; bias [64]; res,out [rows][64];

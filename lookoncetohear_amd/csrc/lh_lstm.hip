@@ -399,6 +399,255 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Recurrence with the following Linear + residual fused in ("lin" kernels): instead of writing the hidden states
+// to HBM for a separate pointwise kernel, every step also multiplies h_{t-1} by the wave's 16 columns of the
+// output projection (6 extra MFMAs on the h fragments it has already read), parks the 16 x 64 product in LDS and,
+// one step later, the row-wise threads add bias + residual and store the finished 256-byte activation rows.
+//   NPASS = 1 (inter path):  out = res + b + W h                                  (tfgridnet_causal.py:534-538)
+//   NPASS = 2 (intra path):  the same workgroup runs the forward direction (out = res + b + W[:, :64] h_fwd)
+//                            and then the reverse direction (out += W[:, 64:] h_bwd) over its sequences, so
+//                            both halves of the bidirectional projection meet in the same rows without any
+//                            inter-workgroup hand-off (:505-516).
+// HBM traffic per block drops from (LSTM 4A + Linear 4A) to <= 5A intra and from (2A + 3A) to 2A inter.
+// ------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
+                                                        const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
+                                                        const float* __restrict__ blin, const float* __restrict__ h0,
+                                                        const float* __restrict__ c0, float* __restrict__ hN,
+                                                        float* __restrict__ cN, float* __restrict__ out, int nseq,
+                                                        int nstep, int sdiv, int so, int si, int ps, int dir,
+                                                        int accumulate) {
+    constexpr int NS = 16 * MT;
+    constexpr int LSP = C + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
+    __shared__ __attribute__((aligned(16))) float ls[2 * NS * LSP];
+    __shared__ __attribute__((aligned(16))) _Float16 wls[4 * 2 * 64 * 16];        // output-projection B image of this pass
+    __shared__ __attribute__((aligned(16))) float hf[NS * LSP];                   // fp32 copy of the newest hidden state
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s0 = blockIdx.x * NS;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int q = tid & 15;
+    const int unit = wave * 16 + l15;
+    constexpr float INV = 1.0f / SPLIT_SCALE;
+
+    auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
+    {
+        const int pass = dir;
+        auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
+        // weights of this pass: gate image in VGPRs, output-projection image in LDS
+        f16x8 wh[4][4], wl[4][4];
+        {
+            const _Float16* wp = w_pk + ((long)(dir * 4 + wave) * 16 * 64 + lane) * 16;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    wh[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16);
+                    wl[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16 + 8);
+                }
+        }
+        for (int i = tid; i < 4 * 2 * 64 * 2; i += 256)
+            *reinterpret_cast<f16x8*>(&wls[i * 8]) = *reinterpret_cast<const f16x8*>(&wlin_pk[i * 8]);
+        float bias[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + unit];
+
+        auto load_x = [&](int it, float4 (&xr)[MT]) {
+            const int p = step_pos(it);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
+                xr[i] = *reinterpret_cast<const float4*>(&x[row_of(s, p) * C + q * 4]);
+            }
+        };
+        auto store_split4 = [&](int buf, int rl, int col, float a, float b, float c, float d) {
+            f16x4 h4, l4;
+            _Float16 th, tl;
+            split_f16(a, th, tl); h4[0] = th; l4[0] = tl;
+            split_f16(b, th, tl); h4[1] = th; l4[1] = tl;
+            split_f16(c, th, tl); h4[2] = th; l4[2] = tl;
+            split_f16(d, th, tl); h4[3] = th; l4[3] = tl;
+            *reinterpret_cast<f16x4*>(&ahi[(buf * NS + rl) * LH_AP + col]) = h4;
+            *reinterpret_cast<f16x4*>(&alo[(buf * NS + rl) * LH_AP + col]) = l4;
+        };
+        auto norm_store_x = [&](int buf, float4 (&xr)[MT]) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rl = (tid + 256 * i) >> 4;
+                float4 v = xr[i];
+                const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+                v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+                const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+                const float rstd = rsqrtf(var + LN_EPS);
+                store_split4(buf, rl, q * 4, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
+            }
+        };
+        // base of the projection's accumulation for the rows of step `it`: pass 0 the residual (= the un-normalised
+        // LSTM input itself), pass 1 the partial sum written by pass 0 (same thread, same rows)
+        auto load_base = [&](int it, float4 (&rr)[MT]) {
+            const int p = step_pos(it);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
+                const float* src = accumulate ? out : x;
+                rr[i] = *reinterpret_cast<const float4*>(&src[row_of(s, p) * C + q * 4]);
+            }
+        };
+        // finished rows of step `it`: base + (bias) + projection parked in ls[buf]
+        auto store_rows = [&](int it, int buf, const float4 (&rr)[MT]) {
+            const int p = step_pos(it);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rl = (tid + 256 * i) >> 4;
+                const int s = min(s0 + rl, nseq - 1);        // tail rows replicate sequence nseq-1: identical bytes
+                const float4 pv = *reinterpret_cast<const float4*>(&ls[(buf * NS + rl) * LSP + q * 4]);
+                *reinterpret_cast<float4*>(&out[row_of(s, p) * C + q * 4]) =
+                    make_float4(rr[i].x + pv.x, rr[i].y + pv.y, rr[i].z + pv.z, rr[i].w + pv.w);
+            }
+        };
+        // P = h W_lin^T for the h tile in A buffer `buf` -> ls[lbuf]   (k-steps 2,3 of the A rows are the h part)
+        const float lbias = accumulate ? 0.0f : blin[unit];       // output bias rides in the accumulator (first pass only)
+        auto lin_tile = [&](int buf, int lbuf) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 am = f32x4{lbias, lbias, lbias, lbias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int ro = (buf * NS + m * 16 + l15) * LH_AP + g4 * 8;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(&wls[((wave * 2 + ks) * 64 + lane) * 16]);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(&wls[((wave * 2 + ks) * 64 + lane) * 16 + 8]);
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + (2 + ks) * 32]);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + (2 + ks) * 32]);
+                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, am, 0, 0, 0);
+                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, ac, 0, 0, 0);
+                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, ac, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ls[(lbuf * NS + m * 16 + g4 * 4 + r) * LSP + unit] = am[r] + ac[r] * INV;
+            }
+        };
+
+        // ---- prologue
+        float creg[MT][4];
+        float4 xr[MT], rr[MT];
+        {
+            load_x(0, xr);
+            norm_store_x(0, xr);
+            load_x(1, xr);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rl = (tid + 256 * i) >> 4;
+                const int s = min(s0 + rl, nseq - 1);
+                float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
+                store_split4(0, rl, C + q * 4, hv.x, hv.y, hv.z, hv.w);
+                rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = min(s0 + m * 16 + g4 * 4 + r, nseq - 1);
+                    creg[m][r] = c0 ? c0[(long)s * H + unit] : 0.0f;
+                }
+        }
+        __syncthreads();
+
+        for (int it = 0; it < nstep; ++it) {
+            const int cur = it & 1, nxt = cur ^ 1;
+            // rows of step it-2 are complete: projection parked in ls[(it-1)&1] one step ago, base fetched one step ago
+            if (it >= 2) store_rows(it - 2, (it - 1) & 1, rr);
+            load_base(it - 1, rr);                        // consumed next iteration (clamped at it = 0: unused)
+            norm_store_x(nxt, xr);
+            load_x(it + 2, xr);
+
+            f32x4 gate[MT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 accm[4], accc[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    accm[g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
+                    accc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const int ro = (cur * NS + m * 16 + l15) * LH_AP + g4 * 8;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) accm[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], accm[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], accc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], accc[g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gate[m][g] = accm[g] + accc[g] * INV;
+            }
+            lin_tile(cur, it & 1);                        // projection of h_{it-1} (at it = 0: of the initial state, unused)
+
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ig = sigmoid_f(gate[m][0][r]);
+                    const float fg = sigmoid_f(gate[m][1][r]);
+                    const float gg = tanh_f(gate[m][2][r]);
+                    const float og = sigmoid_f(gate[m][3][r]);
+                    const float cc = fg * creg[m][r] + ig * gg;
+                    creg[m][r] = cc;
+                    const float hv = og * tanh_f(cc);
+                    const int rl = m * 16 + g4 * 4 + r;
+                    _Float16 th, tl;
+                    split_f16(hv, th, tl);
+                    ahi[(nxt * NS + rl) * LH_AP + C + unit] = th;
+                    alo[(nxt * NS + rl) * LH_AP + C + unit] = tl;
+                    hf[rl * LSP + unit] = hv;
+                }
+            __syncthreads();
+        }
+
+        // ---- drain: rows of the last two steps
+        if (nstep >= 2) store_rows(nstep - 2, (nstep - 1) & 1, rr);
+        load_base(nstep - 1, rr);
+        lin_tile(nstep & 1, nstep & 1);                   // projection of h_{nstep-1}
+        __syncthreads();
+        store_rows(nstep - 1, nstep & 1, rr);
+        if (hN) {                                         // hf was last written before the final loop barrier
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rl = (tid + 256 * i) >> 4;
+                if (s0 + rl < nseq)
+                    *reinterpret_cast<float4*>(&hN[(long)(s0 + rl) * H + q * 4]) =
+                        *reinterpret_cast<const float4*>(&hf[rl * LSP + q * 4]);
+            }
+        }
+        if (cN) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = s0 + m * 16 + g4 * 4 + r;
+                    if (s < nseq) cN[(long)s * H + unit] = creg[m][r];
+                }
+        }
+    }
+}
+
+template <int MT>
+static int launch_lstm_lin(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                           const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep,
+                           int sdiv, int so, int si, int ps, int dir, int accumulate, hipStream_t st) {
+    constexpr int NS = 16 * MT;
+    hipLaunchKernelGGL((k_ln_lstm_lin<MT>), dim3((nseq + NS - 1) / NS), dim3(256), 0, st, x, (const _Float16*)w_pk, b_sum,
+                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Software-pipelined split-precision kernel (NS = 16 sequences per workgroup): the gate pre-activations are
 //     gates_t = [LN(x_t) W_ih^T + b]  +  h_{t-1} W_hh^T
 // and only the second term sits on the recurrence.  The x-term of step t+1 is computed inside step t, in the
@@ -710,4 +959,28 @@ extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* 
                               (hipStream_t)stream);
     return launch_lstm<1>(x, ln_w, ln_b, w_f32, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
                           (hipStream_t)stream);
+}
+
+// Fused variants: LayerNorm + (Bi)LSTM + output Linear + residual (split-precision mode only).
+extern "C" int lh_intra_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk,
+                              const float* blin, float* out, int n_frames, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !w_pk || !b_sum || !wlin_pk || !blin || !out || n_frames <= 0 || x == out) return LH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // sequence = frame (b,t), step = frequency bin; forward launch then reverse launch (accumulating)
+    int rc = LH_OK;
+    for (int dir = 0; dir < 2 && rc == LH_OK; ++dir)
+        rc = launch_lstm_lin<1>(x, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, nullptr, nullptr,
+                                nullptr, nullptr, out, n_frames, NF, 1, NF, 0, 1, dir, dir, st);
+    return rc;
+}
+
+extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk,
+                              const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out,
+                              int B, int T, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !w_pk || !b_sum || !wlin_pk || !blin || !h0 || !c0 || !hN || !cN || !out || B <= 0 || T <= 0) return LH_ERR_ARG;
+    if (h0 == hN || c0 == cN || x == out) return LH_ERR_ARG;
+    return launch_lstm_lin<1>(x, w_pk, b_sum, wlin_pk, blin, h0, c0, hN, cN, out, B * NF, T, NF, T * NF, 1, NF, 0, 0,
+                              (hipStream_t)stream);
 }

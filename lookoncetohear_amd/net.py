@@ -146,6 +146,8 @@ class Net(nn.Module):
         # contraction arithmetic of the recurrent kernels: "f16x3" = split-precision fp16 MFMA (hi/lo operands,
         # ~22 mantissa bits, ~5x the fp32-MFMA rate), "f32" = exact fp32 MFMA.  LOOKONCE_GEMM overrides.
         self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
+        # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
+        self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
         self._pack_key = None
         self._packed = None
         self._ws: Dict[tuple, dict] = {}
@@ -287,18 +289,25 @@ class Net(nn.Module):
             for i in range(self.n_blocks):
                 bp = pk["blocks"][i]
                 bs = state["gridnet_bufs"][f"buf{i}"]
-                # intra: LN + BiLSTM over frequency -> Linear(128->64) + residual
-                lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra" + wkey]),
-                         P(bp["intra" + bkey]), P(hbuf), Bn * T, mode, st)
-                lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
-                         2 * H_, st)
-                # inter: LN + causal LSTM over time with carried state -> Linear(64->64) + residual
                 h0, c0 = c32(bs["h0"]), c32(bs["c0"])
                 hN, cN = new(h0), new(c0)
-                lib.call("lh_ln_lstm_inter", P(xb), P(bp["inter_ln_w"]), P(bp["inter_ln_b"]), P(bp["inter" + wkey]),
-                         P(bp["inter" + bkey]), P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, mode, st)
-                lib.call("lh_linear_res", P(hbuf), P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(xb), P(xc), rows,
-                         H_, st)
+                if mode == 1 and self.fuse_linear:
+                    # fused kernels: LN + (Bi)LSTM + Linear + residual, no hidden-state round trip through HBM
+                    lib.call("lh_intra_block", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
+                             P(bp["intra_lin_b"]), P(xb), Bn * T, st)
+                    lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
+                             P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
+                else:
+                    # intra: LN + BiLSTM over frequency -> Linear(128->64) + residual
+                    lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra" + wkey]),
+                             P(bp["intra" + bkey]), P(hbuf), Bn * T, mode, st)
+                    lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
+                             2 * H_, st)
+                    # inter: LN + causal LSTM over time with carried state -> Linear(64->64) + residual
+                    lib.call("lh_ln_lstm_inter", P(xb), P(bp["inter_ln_w"]), P(bp["inter_ln_b"]), P(bp["inter" + wkey]),
+                             P(bp["inter" + bkey]), P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, mode, st)
+                    lib.call("lh_linear_res", P(hbuf), P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(xb), P(xc), rows,
+                             H_, st)
                 # attention: history rows in, Q/K/V, local attention (head merge fused), projection + LN + residual
                 ws["kx"][:, :hist, :self.E * F_].copy_(bs["K_buf"])
                 ws["vx"][:, :hist].copy_(bs["V_buf"])

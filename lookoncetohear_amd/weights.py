@@ -109,6 +109,9 @@ def pack_block(sd: dict, pre: str) -> dict:
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
     out["intra_lin_w"], out["intra_lin_b"] = pack_linear_f16x3(g("intra_linear.weight")), g("intra_linear.bias")
+    # fused kernels: per-direction halves of the bidirectional projection [2 passes][4][2][64][2][8]
+    out["intra_lin_w2"] = torch.stack([pack_linear_f16x3(g("intra_linear.weight")[:, :64].contiguous()),
+                                       pack_linear_f16x3(g("intra_linear.weight")[:, 64:].contiguous())])
     out["inter_ln_w"], out["inter_ln_b"] = g("inter_norm.norm.weight"), g("inter_norm.norm.bias")
     out["inter_w"] = pack_lstm(g("inter_rnn.weight_ih_l0"), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["inter_b"] = g("inter_rnn.bias_ih_l0") + g("inter_rnn.bias_hh_l0")
