@@ -291,18 +291,23 @@ class Net(nn.Module):
                 bs = state["gridnet_bufs"][f"buf{i}"]
                 h0, c0 = c32(bs["h0"]), c32(bs["c0"])
                 hN, cN = new(h0), new(c0)
-                if mode == 1 and self.fuse_linear:
-                    # fused kernels: LN + (Bi)LSTM + Linear + residual, no hidden-state round trip through HBM
+                fuse = mode == 1 and self.fuse_linear
+                # the fused intra path runs the two directions as consecutive launches (the reverse one accumulates into
+                # the forward one's rows): worth it once a single direction fills the GPU, otherwise the unfused kernel
+                # (both directions concurrently) has half the latency (streaming, batch 1)
+                if fuse and Bn * T >= 8192:
                     lib.call("lh_intra_block", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
                              P(bp["intra_lin_b"]), P(xb), Bn * T, st)
-                    lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
-                             P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
                 else:
                     # intra: LN + BiLSTM over frequency -> Linear(128->64) + residual
                     lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra" + wkey]),
                              P(bp["intra" + bkey]), P(hbuf), Bn * T, mode, st)
                     lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
                              2 * H_, st)
+                if fuse:
+                    lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
+                             P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
+                else:
                     # inter: LN + causal LSTM over time with carried state -> Linear(64->64) + residual
                     lib.call("lh_ln_lstm_inter", P(xb), P(bp["inter_ln_w"]), P(bp["inter_ln_b"]), P(bp["inter" + wkey]),
                              P(bp["inter" + bkey]), P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, mode, st)
