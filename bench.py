@@ -44,6 +44,8 @@ KERNEL_WORK = {
     # fused kernels: LSTM + output projection + residual (two launches per block for the bidirectional intra path)
     "lh_intra_block": dict(flops=625 * 97 * 2 * (2 * 128 * 256 + 128 * 64), bytes=5 * 15.52e6, bound="mfma"),
     "lh_inter_block": dict(flops=625 * 97 * 2 * (128 * 256 + 64 * 64), bytes=2 * 15.52e6, bound="mfma"),
+    "lh_intra_block8": dict(flops=625 * 97 * 2 * (2 * 128 * 256 + 128 * 64), bytes=5 * 15.52e6, bound="mfma"),
+    "lh_inter_block8": dict(flops=625 * 97 * 2 * (128 * 256 + 64 * 64), bytes=2 * 15.52e6, bound="mfma"),
     "lh_linear_res": dict(flops=625 * 97 * 2 * 96 * 64, bytes=(1.5 + 1 + 1) * 15.52e6, bound="hbm"),   # avg K=96
     "lh_qkv_proj_ln": dict(flops=625 * 97 * 2 * 64 * 112, bytes=15.52e6 + 2 * 5.82e6 + 15.52e6, bound="hbm"),
     "lh_local_attn": dict(flops=4 * 625 * 50 * 2 * (582 + 1552), bytes=2 * 5.82e6 + 2 * 15.52e6, bound="hbm"),

@@ -109,6 +109,15 @@ int lh_inter_block(const float* x, const void* w_pk, const float* b_sum, const v
                    const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,
                    lh_stream_t stream);
 
+/* Same contracts as lh_intra_block / lh_inter_block on the 8-wave kernel (gate columns split over eight waves, four
+ * waves per SIMD); w8_pk = fp16 hi/lo image [dirs][8 waves][2 tiles][4 ksteps][64 lanes][16] (weights.py
+ * pack_lstm8_f16x3). */
+int lh_intra_block8(const float* x, const void* w8_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                    float* out, int n_frames, lh_stream_t stream);
+int lh_inter_block8(const float* x, const void* w8_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                    const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,
+                    lh_stream_t stream);
+
 /* Row-wise Linear(K->64) + bias + residual:  out[r][:] = res[r][:] + W h[r][:] + b.
  * Replaces intra_linear + residual (tfgridnet_causal.py:513-516, K=128) and inter_linear + view/transpose +
  * residual (:534-538, K=64).   h [rows][K]; bias [64]; res,out [rows][64];

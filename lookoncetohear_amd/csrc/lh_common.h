@@ -49,6 +49,11 @@ __device__ __forceinline__ float row_ror_add(float v) {
     const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false);
     return v + __builtin_bit_cast(float, r);
 }
+// value of the lane N positions to the left (cyclic) inside each aligned row of 16 lanes; N = 8 swaps lane l with l ^ 8
+template <int N>
+__device__ __forceinline__ float row_ror_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
 // sum over aligned groups of 16 lanes (every lane of the group gets the total)
 __device__ __forceinline__ float group16_sum(float v) {
     v = row_ror_add<8>(v);

@@ -70,6 +70,26 @@ def pack_lstm_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo], dim=4).contiguous()             # [4,4,4,64,2,8]
 
 
+def pack_lstm8_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """8-wave image: [8 waves, 2 tiles, 4 ksteps, 64 lanes, 2 (hi|lo), 8] fp16.  Wave w owns hidden units 8w..8w+7;
+    column l & 15 of tile t is gate 2t + ((l & 15) >> 3) (tile 0 = [i | f], tile 1 = [g | o]) of unit 8w + (l & 7);
+    k = ks*32 + (l >> 4)*8 + j over [x(64) | h(64)]."""
+    H = w_hh.shape[1]
+    assert H == 64 and tuple(w_ih.shape) == (4 * H, 64)
+    wcat = torch.cat([w_ih, w_hh], dim=1).float()
+    dev = wcat.device
+    lane = torch.arange(64, device=dev)
+    wave = torch.arange(8, device=dev)[:, None, None, None, None]
+    tile = torch.arange(2, device=dev)[None, :, None, None, None]
+    ks = torch.arange(4, device=dev)[None, None, :, None, None]
+    j = torch.arange(8, device=dev)[None, None, None, None, :]
+    l15 = (lane & 15)[None, None, None, :, None]
+    col = (tile * 2 + (l15 >> 3)) * H + wave * 8 + (l15 & 7)
+    k = ks * 32 + (lane >> 4)[None, None, None, :, None] * 8 + j
+    hi, lo = split_f16(wcat[col, k])
+    return torch.stack([hi, lo], dim=4).contiguous()
+
+
 def pack_linear_f16x3(w: torch.Tensor) -> torch.Tensor:
     """w [N, K] -> split-precision B image [N/16, K/32, 64 lanes, 2 (hi|lo), 8] fp16 for v_mfma_f32_16x16x32_f16:
     lane l of (n-tile nt, k-step ks) holds W[nt*16 + (l & 15)][ks*32 + (l >> 4)*8 + j], j = 0..7."""
@@ -105,6 +125,10 @@ def pack_block(sd: dict, pre: str) -> dict:
         fold_b(g("intra_rnn.weight_ih_l0_reverse"), ib, g("intra_rnn.bias_ih_l0_reverse"),
                g("intra_rnn.bias_hh_l0_reverse"))])
     out["inter_w16"] = pack_lstm_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
+    out["intra_w8"] = torch.stack([
+        pack_lstm8_f16x3(fold_w(g("intra_rnn.weight_ih_l0"), iw), g("intra_rnn.weight_hh_l0")),
+        pack_lstm8_f16x3(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw), g("intra_rnn.weight_hh_l0_reverse"))])
+    out["inter_w8"] = pack_lstm8_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["inter_b16"] = fold_b(g("inter_rnn.weight_ih_l0"), eb, g("inter_rnn.bias_ih_l0"), g("inter_rnn.bias_hh_l0"))
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
