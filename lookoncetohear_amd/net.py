@@ -148,8 +148,9 @@ class Net(nn.Module):
         self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
-        # fused recurrence kernel flavour: 8 = gate columns over eight waves (four waves per SIMD), 4 = four waves
-        self.lstm_waves = int(os.environ.get("LOOKONCE_LSTM_WAVES", "8"))
+        # fused recurrence kernel flavour: 4 = four waves x 64 gate columns (default); 8 = experimental eight-wave split
+        # (four waves per SIMD) that measured 1.4-1.6x slower on MI355X (register spills, wider barrier), kept for A/B
+        self.lstm_waves = int(os.environ.get("LOOKONCE_LSTM_WAVES", "4"))
         self.fuse_intra_min_frames = 8192
         self._pack_key = None
         self._packed = None
