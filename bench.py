@@ -129,6 +129,83 @@ def bench_stream(args, net, dev, rank, world):
                        "batch_per_gpu": B, "gemm_mode": net.gemm_mode}}))
 
 
+def bench_embed(args, dev, rank, world, dist):
+    """BASELINE configs[4]: the enrollment d-vector embedder (configs/embed.json) on 64 x 5 s binaural clips per GPU.
+    A step = one forward of the batch; utterances shard across ranks with no exchange at all (embeddings stay local)."""
+    from lookoncetohear_amd import synth
+    from lookoncetohear_amd.embed_net import EmbedTFGridNet
+    from oracle import embedder_oracle as E
+    B = 64 if args.batch == 32 else args.batch
+    cfg = E.ECfg(**E.EMBED_PARAMS)
+    net = EmbedTFGridNet(**E.EMBED_PARAMS).eval()
+    net.load_state_dict(E.synthetic_state_dict(cfg, 0), strict=True)
+    net = net.to(dev)
+    uniq = min(B, 8)
+    x = synth.batch([rank * B + i for i in range(uniq)], 80000)["mixture"]
+    x = x.repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous().to(dev)
+    T = 80000 // 64 + 1
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(x)
+        torch.cuda.synchronize()
+        net._prof = []
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            emb = net(x)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof, net._prof = net._prof, None
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    per = {}
+    for name, e0, e1 in prof:
+        per.setdefault(name, []).append(e0.elapsed_time(e1))
+    kern = {k: dict(launches=len(v), total_ms=sum(v), avg_ms=sum(v) / len(v)) for k, v in per.items()}
+    if rank != 0:
+        return
+    # algorithmic fp32-equivalent FLOPs of the dominant candidates, per clip (T = 1251 frames, 65 bins)
+    nblk = cfg.nblk
+    work = {
+        "lh_emb_attn_block": 2.0 * T * 65 * 64 * (128 + 64) + 4 * (2.0 * T * T * 520 + 2.0 * T * T * 1040),
+        "lh_emb_axis.intra": 2.0 * T * 62 * (256 * 512 + 128 * 512) + 2.0 * T * 65 * 512 * 64,
+        "lh_emb_axis.inter": 2.0 * 65 * (T - 3) * (256 * 512 + 128 * 512) + 2.0 * T * 65 * 512 * 64,
+        "lh_emb_head": 2.0 * T * 4160 * 256,
+        "lh_emb_frontend": 2.0 * T * 2 * 128 * 130 + 2.0 * T * 65 * 36 * 64,
+    }
+    dom = max(kern, key=lambda k: kern[k]["total_ms"])
+    ach = work[dom] * B / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+    exact = dom == "lh_emb_frontend"
+    peak = PEAK_FP32_MFMA_TFLOPS if exact else PEAK_F16_MFMA_TFLOPS
+    cpu = None
+    if not args.no_cpu_baseline:
+        t1 = time.perf_counter()
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        xs = x[:1, :, :16000].cpu()
+        E.forward(cfg, E.synthetic_state_dict(cfg, 0), xs)
+        dt = time.perf_counter() - t1
+        cpu = {"value": 251 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "oracle/embedder_oracle.py (torch CPU fp32), 1 x 1 s clip = 251 frames, one pass"}
+    print(json.dumps({
+        "metric": "enrollment embedder frames_per_sec (5 s 16 kHz binaural clips, 1251 STFT frames each)",
+        "value": world * B * args.steps * T / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "clips_per_sec": world * B * args.steps / elapsed,
+        "config": {"workload": f"BASELINE configs[4]: configs/embed.json d-vector embedder, {B} x 5 s clips per GPU "
+                               "(random-init weights; oracle parity unpinned, see DESIGN.md)", "batch_per_gpu": B},
+        "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                     "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"],
+                     "note": "algorithmic fp32-equivalent FLOPs" + ("" if exact else "; f16x3 GEMMs + fp32-MFMA attention")},
+        "cpu_baseline": cpu, "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kern.items()},
+        "embedding_norm_mean": float(emb.norm(dim=1).mean())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,7 +213,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE configs[2] = 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="offline", choices=["offline", "stream"],
+    ap.add_argument("--mode", default="offline", choices=["offline", "stream", "embed"],
                     help="offline = BASELINE configs[2] (default, the headline line); stream = configs[1]: 8 ms chunks, "
                          "carried state, HIP-graph replay per chunk (a step = one chunk)")
     ap.add_argument("--gemm", default=None, choices=["f32", "f16x3"], help="override Net.gemm_mode (A/B runs)")
@@ -156,6 +233,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)     # RCCL over xGMI
 
     from lookoncetohear_amd import synth, _cabi
+    if args.mode == "embed":
+        _cabi.load()
+        return bench_embed(args, dev, rank, world, dist)
     from lookoncetohear_amd.net import Net
     from lookoncetohear_amd.metrics import metric_sums_device
     from oracle import tfgridnet_oracle as O

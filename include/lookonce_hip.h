@@ -170,6 +170,50 @@ int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_bu
                     float* istft_buf_out, const float* wdec_pk, const float* bdec, const float* wfb_dec,
                     float* wave_out, int B, int T, lh_stream_t stream);
 
+/* ---- enrollment embedder (reference src/models/tfgridnet_orig/tfgridnet.py:88-127 + espnet2 TF-GridNet trunk) ----
+ * Front end, tfgridnet.py:109-117: x / std(x) (unbiased, over samples and mics), STFT(n_fft 128, hop 64, hann, centred
+ * with reflect padding), re/im channel stacking, Conv2d(4->64, 3x3, padding 1), GroupNorm(1, 64).
+ *   x [B][2][n_samples]; inv_std [B] (out); wfb_pk fp32 MFMA image [9][32][64] of the windowed DFT rows [128 x 130];
+ *   wconv_pk [4][9][64] of conv.0.weight as [36 taps] x [64]; bconv, gn_w, gn_b [64];
+ *   gn_part fp64 scratch [B * ceil(T/14)][2]; z [B][T][65][64] out, T = n_samples/64 + 1
+ */
+int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_pk, const float* wconv_pk, const float* bconv,
+                    const float* gn_w, const float* gn_b, double* gn_part, float* z, int B, int T, int n_samples,
+                    lh_stream_t stream);
+
+/* One axis path of an espnet2 GridNetBlock of the embedder (intra: inter = 0, sequences = frames, scan over the 65
+ * bins; inter = 1: sequences = bins, scan over time): LayerNorm(C) -> unfold(4) -> BiLSTM(256 -> 64) ->
+ * ConvTranspose1d(128 -> 64, 4) -> + residual, as three launches (input GEMM over all windows, recurrence, gather-GEMM).
+ *   x, out [B][T][65][64] (no alias); wih_pk fp16 hi/lo image [32][8][64][16] (both directions, LN affine folded,
+ *   features window-major, columns (dir, unit, gate)); bih [512]; whh_pk [2][4][4][2][64][16]; wct_pk [4][16][64][16]
+ *   of the taps as [64] x [4*128]; bct [64]; gx scratch [nseq*P][512]; hbuf scratch [nseq*P][128] (P = L - 3)
+ */
+int lh_emb_axis(const float* x, const void* wih_pk, const float* bih, const void* whh_pk, const void* wct_pk,
+                const float* bct, float* gx, float* hbuf, float* out, int B, int T, int inter, lh_stream_t stream);
+
+/* Enrollment embedder, attention branch of one GridNetBlock (espnet2 GridNetBlock.forward attention part, restated in
+ * oracle/embedder_oracle.py:149-168): per-head Q/K/V 1x1 conv + PReLU + LayerNorm over (channel, bin), full T x T
+ * softmax attention per (head, utterance), head merge, attn_concat_proj (1x1 conv + PReLU + LayerNorm) + residual.
+ *   y2, out  [B][T][65][64];  merged scratch [B][T][65][64];  q, k scratch [4B][T][520];  v scratch [4B][T][1040]
+ *   wqkv_pk  fp16 hi/lo image [8][2][64][16] of the stacked conv weights [128 x 64] (Q h*8+e | K | V h*16+v)
+ *   bqkv, slopes [128] (PReLU slope of each output column's head conv)
+ *   lnq_*, lnk_* [4][520], lnv_* [4][1040]: LayerNorm affine re-ordered to (bin*d + channel)
+ *   wproj_pk [4][2][64][16]; bproj [64]; slope_p [1]; lnp_* [4160] re-ordered to (bin*64 + channel)
+ */
+int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const float* bqkv, const float* slopes,
+                      const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                      const float* lnv_w, const float* lnv_b, const void* wproj_pk, const float* bproj,
+                      const float* slope_p, const float* lnp_w, const float* lnp_b, float* q, float* k, float* v,
+                      float* merged, float* out, int B, int T, lh_stream_t stream);
+
+/* Enrollment embedder head (reference src/models/tfgridnet_orig/tfgridnet.py:120-127): Linear(65*64 -> 256) per
+ * frame, LayerNorm(256), mean over frames.
+ *   z [B][T][65][64];  w_pk fp16 hi/lo image [16][130][64][16] of the weight with inputs re-ordered to (bin*64 + c)
+ *   bias, ln_w, ln_b [256];  part scratch [B][ceil(T/64)][256];  emb [B][256]
+ */
+int lh_emb_head(const float* z, const void* w_pk, const float* bias, const float* ln_w, const float* ln_b,
+                float* part, float* emb, int B, int T, lh_stream_t stream);
+
 /* Eval metrics on the device (reference src/ts_hear_test.py:139-146, torchmetrics SI-SNR restated): per utterance
  * output_sisnr, si_snr_i (both averaged over the 2 channels) and cosine(embedding, embedding_gt); fp64 moments.
  *   outputs, target, mixture [B][2][n_samples]; emb, emb_gt [B][emb_dim]

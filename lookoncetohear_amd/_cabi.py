@@ -32,6 +32,10 @@ SIGNATURES = {
     "lh_local_attn": [_P] * 4 + [_I, _I, _P],
     "lh_proj_ln_res": [_P] * 9 + [_I, _I, _P],
     "lh_deconv_istft": [_P] * 9 + [_I, _I, _P],
+    "lh_emb_frontend": [_P] * 9 + [_I, _I, _I, _P],
+    "lh_emb_axis": [_P] * 9 + [_I, _I, _I, _P],
+    "lh_emb_attn_block": [_P] * 20 + [_I, _I, _P],
+    "lh_emb_head": [_P] * 7 + [_I, _I, _P],
     "lh_metric_sums": [_P] * 8 + [_I, _I, _I, _P],
 }
 ERRORS = {1: "LH_ERR_ARG", 2: "LH_ERR_UNSUPPORTED", 3: "LH_ERR_LAUNCH"}

@@ -1,0 +1,1036 @@
+// Enrollment embedder (reference src/models/tfgridnet_orig/tfgridnet.py:88-127 on top of the
+// espnet2 TF-GridNet trunk, see oracle/embedder_oracle.py): kernels that have no counterpart in the separator path.
+//   k_emb_std / k_emb_stft_conv / k_emb_gn_apply   std-normalise, STFT(128/64, hann, centred) + Conv2d 3x3 + GroupNorm
+//   k_emb_gx / k_emb_lstm / k_emb_convt_res        LN + unfold(4) input GEMM, BiLSTM recurrence, ConvTranspose1d + res
+//   k_emb_attn                                     full (T x T) attention with online softmax, head merge fused
+//   k_emb_head / k_emb_head_mean                   Linear(65*64 -> 256) + LayerNorm + mean over frames
+// Activations are channel-last [B][T][65][64] like the separator's.
+#include "lh_common.h"
+
+namespace lh {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int EF = 65;            // n_fft/2 + 1
+constexpr int EK = 2 * EF;        // 130 filter rows (re | im)
+constexpr int ENFFT = 128;
+constexpr int EHOP = 64;
+constexpr int EKS = 4;            // emb_ks (unfold / ConvTranspose1d kernel)
+constexpr int EE = 8;             // ceil(512 / 65)
+constexpr int EDQK = EF * EE;     // 520
+constexpr int EDV = EF * VD;      // 1040
+constexpr float ESPLIT = 2048.0f;
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1 / std(x[b]) over all samples of all microphones, unbiased (torch.std default) — tfgridnet_orig/tfgridnet.py:109
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_emb_std(const float* __restrict__ x, float* __restrict__ inv_std, int n) {
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = x + (long)blockIdx.x * n;
+    double s = 0.0, ss = 0.0;
+    for (int i = tid; i < n; i += 256) { const double v = xb[i]; s += v; ss += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    if (tid == 0) {
+        const double S = red[0][0] + red[0][1] + red[0][2] + red[0][3], SS = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double var = (SS - S * S / n) / (n - 1);
+        inv_std[blockIdx.x] = (float)(1.0 / sqrt(var));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// STFT (n_fft 128, hop 64, periodic hann folded into the filter rows, centre = reflect padding) + re/im channel
+// stacking + Conv2d(4 -> 64, 3x3, zero padding 1 in time AND frequency) on fp32 MFMA; also the per-tile partial
+// sums of the GroupNorm(1, 64) that follows.  Same structure as k_stft_conv_in (lh_frontend.hip): 14 output frames
+// per tile = 16 STFT frames (one halo frame each side), filterbank resident in VGPRs as B fragments.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int EM_TT = 14;
+constexpr int EM_NJ = 16;
+constexpr int EM_KC = ENFFT / 4;               // 32
+constexpr int EM_KP = EM_KC + 4;               // 36 floats = 9 x 16 B
+constexpr int EM_SROW = EF + 3;                // [0] pad, [1..65] bins, [66] pad, [67] unused
+constexpr int EM_NT = (EK + 15) / 16;          // 9 filter-row tiles
+constexpr int EM_OP = C + 4;
+
+__global__ void __launch_bounds__(256, 1) k_emb_stft_conv(const float* __restrict__ x, const float* __restrict__ inv_std,
+                                                           const float* __restrict__ wfb_pk, const float* __restrict__ wc_pk,
+                                                           const float* __restrict__ bc, float* __restrict__ z,
+                                                           double* __restrict__ gn_part, int B, int T, int n_samples) {
+    __shared__ __attribute__((aligned(16))) float aimg[NMIC * 4 * EM_NJ * EM_KP];
+    __shared__ float spec[2 * NMIC][EM_NJ][EM_SROW];
+    __shared__ __attribute__((aligned(16))) float outs[EF * EM_OP];
+    __shared__ double gred[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+
+    float wf[3][EM_KC];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int nt = min(wave + 4 * i, EM_NT - 1);
+#pragma unroll
+        for (int ks = 0; ks < EM_KC; ++ks) wf[i][ks] = wfb_pk[((long)nt * EM_KC + ks) * 64 + lane];
+    }
+    float wcv[9];
+    int aoff[9];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
+        wcv[ks] = wc_pk[(wave * 9 + ks) * 64 + lane];
+        const int qq = g4 * 9 + ks, ch = qq / 9, kt = (qq % 9) / 3, kf = qq % 3;
+        aoff[ks] = (ch * EM_NJ + kt) * EM_SROW + kf;
+    }
+    const float cbias = bc[wave * 16 + l15];
+    for (int i = tid; i < 2 * NMIC * EM_NJ; i += 256) {
+        float* row = &spec[0][0][0] + i * EM_SROW;
+        row[0] = 0.0f; row[EF + 1] = 0.0f; row[EF + 2] = 0.0f;
+    }
+
+    const int tiles_per_b = (T + EM_TT - 1) / EM_TT;
+    for (int tile = blockIdx.x; tile < B * tiles_per_b; tile += gridDim.x) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile % tiles_per_b) * EM_TT;
+        const int nt_out = min(EM_TT, T - t0);
+        const float sc = inv_std[b];
+        __syncthreads();
+
+        // frames t0-1 .. t0+14; frame t = padded samples t*64 .. +127, padded[i] = x[reflect(i - 64)]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const int m = e / (EM_NJ * 32), j = (e / 32) % EM_NJ, c4 = e % 32;
+            const int t = t0 - 1 + j;
+            const float* xb = x + ((long)b * NMIC + m) * n_samples;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < T) {
+                const int i0 = t * EHOP + c4 * 4 - ENFFT / 2;
+                if (i0 >= 0 && i0 + 3 < n_samples && ((n_samples | i0) & 3) == 0) {
+                    v = *reinterpret_cast<const float4*>(&xb[i0]);
+                } else {
+                    float tmp[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int idx = i0 + u;
+                        if (idx < 0) idx = -idx;
+                        if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
+                        tmp[u] = xb[idx];
+                    }
+                    v = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                }
+                v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            }
+            *reinterpret_cast<float4*>(&aimg[((m * 4 + c4 / 8) * EM_NJ + j) * EM_KP + (c4 % 8) * 4]) = v;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int m = 0; m < NMIC; ++m) {
+            float av[EM_KC];
+            const float* arow = &aimg[((m * 4 + g4) * EM_NJ + l15) * EM_KP];
+#pragma unroll
+            for (int qq = 0; qq < EM_KC / 4; ++qq) {
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
+                av[qq * 4 + 0] = a4.x; av[qq * 4 + 1] = a4.y; av[qq * 4 + 2] = a4.z; av[qq * 4 + 3] = a4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int nt = wave + 4 * i;
+                if (nt < EM_NT) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < EM_KC; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wf[i][ks], acc, 0, 0, 0);
+                    const int k = nt * 16 + l15;
+                    if (k < EK) {
+                        const int ch = (k / EF) * NMIC + m, f = k % EF;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = g4 * 4 + r, t = t0 - 1 + j;
+                            spec[ch][j][1 + f] = (t >= 0 && t < T) ? acc[r] : 0.0f;      // zero padding in time
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        float gs = 0.f, gss = 0.f;
+        for (int jt = 0; jt < nt_out; ++jt) {
+            f32x4 acc[5];
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) acc[mt] = f32x4{cbias, cbias, cbias, cbias};
+            const float* sp = &spec[0][0][0] + jt * EM_SROW;
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    const int f = min(mt * 16 + l15, EF - 1);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sp[aoff[ks] + f], wcv[ks], acc[mt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = mt * 16 + g4 * 4 + r;
+                    if (f < EF) { outs[f * EM_OP + wave * 16 + l15] = acc[mt][r]; gs += acc[mt][r]; gss += acc[mt][r] * acc[mt][r]; }
+                }
+            __syncthreads();
+            float* dst = z + (((long)b * T + t0 + jt) * EF) * C;
+            for (int e = tid; e < EF * 16; e += 256)
+                *reinterpret_cast<float4*>(&dst[e * 4]) = *reinterpret_cast<const float4*>(&outs[(e >> 4) * EM_OP + (e & 15) * 4]);
+            __syncthreads();
+        }
+        // GroupNorm partial sums of this tile (fp64)
+        double ds = gs, dss = gss;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dss += __shfl_xor(dss, o); }
+        if (lane == 0) { gred[0][wave] = ds; gred[1][wave] = dss; }
+        __syncthreads();
+        if (tid == 0) {
+            gn_part[(long)tile * 2 + 0] = gred[0][0] + gred[0][1] + gred[0][2] + gred[0][3];
+            gn_part[(long)tile * 2 + 1] = gred[1][0] + gred[1][1] + gred[1][2] + gred[1][3];
+        }
+    }
+}
+
+// GroupNorm(1, 64) over (C, T, F) of one utterance, affine per channel; in place.  grid (chunks, B)
+__global__ void __launch_bounds__(256) k_emb_gn_apply(float* __restrict__ z, const double* __restrict__ gn_part,
+                                                      const float* __restrict__ gw, const float* __restrict__ gb, int T) {
+    __shared__ float stat[2];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tiles_per_b = (T + EM_TT - 1) / EM_TT;
+    if (tid == 0) {
+        double s = 0.0, ss = 0.0;
+        for (int i = 0; i < tiles_per_b; ++i) { s += gn_part[((long)b * tiles_per_b + i) * 2]; ss += gn_part[((long)b * tiles_per_b + i) * 2 + 1]; }
+        const double n = (double)T * EF * C, mean = s / n, var = ss / n - mean * mean;
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + (double)LN_EPS));
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    const int c4 = tid & 15;
+    const float4 w4 = *reinterpret_cast<const float4*>(&gw[c4 * 4]);
+    const float4 b4 = *reinterpret_cast<const float4*>(&gb[c4 * 4]);
+    const long n4 = (long)T * EF * 16;
+    float* zb = z + (long)b * T * EF * C;
+    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = *reinterpret_cast<float4*>(&zb[i * 4]);
+        v.x = (v.x - mean) * rstd * w4.x + b4.x; v.y = (v.y - mean) * rstd * w4.y + b4.y;
+        v.z = (v.z - mean) * rstd * w4.z + b4.z; v.w = (v.w - mean) * rstd * w4.w + b4.w;
+        *reinterpret_cast<float4*>(&zb[i * 4]) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Axis paths of the espnet2 GridNetBlock (intra = along frequency, inter = along time):
+//   LayerNorm over C -> unfold(4, stride 1) -> BiLSTM(256 -> 64) -> ConvTranspose1d(128 -> 64, 4) -> + residual.
+// The 256-wide input projection is not on the recurrence, so it runs as one dense split-precision GEMM over all
+// (sequence, window) rows (k_emb_gx: LN fused into the A staging, LN affine folded into the packed weights, output
+// columns stored in the recurrent kernel's accumulator order); the recurrence (k_emb_lstm) then only carries the
+// 64 x 256 hidden-to-hidden product, and the transposed conv is a K = 4*128 gather-GEMM with the residual add.
+// ---------------------------------------------------------------------------------------------------------------
+template <int RP>
+__device__ __forceinline__ int e_slot(int blk, int row) { return (blk * RP + (row ^ (blk & 7))) * 8; }
+template <int RP>
+__device__ __forceinline__ int e_index(int row, int k) { return e_slot<RP>((k >> 5) * 4 + ((k >> 3) & 3), row) + (k & 7); }
+
+template <int RP>
+__device__ __forceinline__ void e_store_split4(_Float16* ahi, _Float16* alo, int row, int k0, float a, float b, float c, float d) {
+    const float x[4] = {a, b, c, d};
+    f16x4 h4, l4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        h4[i] = h;
+        l4[i] = (_Float16)((x[i] - (float)h) * ESPLIT);
+    }
+    const int idx = e_index<RP>(row, k0);
+    *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
+    *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
+}
+
+template <int RP, int KS>
+__device__ __forceinline__ f32x4 e_mma(const _Float16* ahi, const _Float16* alo, int m, int g4, int l15,
+                                        const f16x8 (&wh)[KS], const f16x8 (&wl)[KS], float bias) {
+    f32x4 am = f32x4{bias, bias, bias, bias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int idx = e_slot<RP>(ks * 4 + g4, m * 16 + l15);
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
+        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
+    }
+    return am + ac * (1.0f / ESPLIT);
+}
+
+// position row (in the [B][T][65][64] activation) of window element k of (sequence s, step p)
+template <bool INTER>
+__device__ __forceinline__ long pos_row(int s, int pk, int T) {
+    if (INTER) return ((long)(s / EF) * T + pk) * EF + (s % EF);      // s = b*65 + f, pk = frame
+    return (long)s * EF + pk;                                           // s = b*T + t,  pk = bin
+}
+
+// Gx[r][chunk*128 ..] = W_ih' unfold(standardise(x))[r] + b'   ; rows r = s*P + p ; grid (persistent, 4 column chunks)
+template <bool INTER>
+__global__ void __launch_bounds__(256, 1) k_emb_gx(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
+                                                   const float* __restrict__ bias, float* __restrict__ gx, int nseq,
+                                                   int P, int T) {
+    constexpr int RP = 64, KS = 8, CSP = 132;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[KS * 4 * RP * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[KS * 4 * RP * 8];
+    __shared__ __attribute__((aligned(16))) float cs[RP * CSP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int chunk = blockIdx.y;
+    f16x8 wh[2][KS], wl[2][KS];
+    float bz[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int nt = chunk * 8 + wave * 2 + i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const _Float16* p = w_pk + ((long)(nt * KS + ks) * 64 + lane) * 16;
+            wh[i][ks] = *reinterpret_cast<const f16x8*>(p);
+            wl[i][ks] = *reinterpret_cast<const f16x8*>(p + 8);
+        }
+        bz[i] = bias[nt * 16 + l15];
+    }
+    const long rows = (long)nseq * P;
+    const int ntiles = (int)((rows + RP - 1) / RP);
+    const int q = tid & 15;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long r0 = (long)tile * RP;
+        __syncthreads();                                   // previous tile's cs reads done
+        // 64 rows x 4 window positions x 64 channels: 16 lanes per position row, LayerNorm over C fused
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pr = ((tid + 256 * (half * 8 + i)) >> 4);          // 0..255 = row*4 + k
+                const long r = min(r0 + (pr >> 2), rows - 1);
+                const int s = (int)(r / P), p = (int)(r % P);
+                v[i] = *reinterpret_cast<const float4*>(&x[pos_row<INTER>(s, p + (pr & 3), T) * C + q * 4]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pr = ((tid + 256 * (half * 8 + i)) >> 4);
+                float4 u = v[i];
+                const float mean = group16_sum(u.x + u.y + u.z + u.w) * (1.0f / C);
+                u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
+                const float var = group16_sum(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.0f / C);
+                const float rstd = rsqrtf(var + LN_EPS);
+                e_store_split4<RP>(ahi, alo, pr >> 2, (pr & 3) * C + q * 4, u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int m = 0; m < RP / 16; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 acc = e_mma<RP, KS>(ahi, alo, m, g4, l15, wh[i], wl[i], bz[i]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[(m * 16 + g4 * 4 + r) * CSP + (wave * 2 + i) * 16 + l15] = acc[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, rr = e >> 5, c4 = e & 31;
+            if (r0 + rr < rows)
+                *reinterpret_cast<float4*>(&gx[(r0 + rr) * 512 + chunk * 128 + c4 * 4]) =
+                    *reinterpret_cast<const float4*>(&cs[rr * CSP + c4 * 4]);
+        }
+    }
+}
+
+// recurrence: gates = Gx[row] + h W_hh^T ; grid (ceil(nseq/16), 2 directions), zero initial state
+constexpr int EL_AP = 144;    // halves per h-image row (64 used): 288-byte stride keeps ds_read_b128 conflict-free
+constexpr int EL_HP = 68;
+__global__ void __launch_bounds__(256, 2) k_emb_lstm(const float* __restrict__ gx, const _Float16* __restrict__ w_pk,
+                                                     float* __restrict__ h_out, int nseq, int P) {
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * 16 * EL_AP];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * 16 * EL_AP];
+    __shared__ __attribute__((aligned(16))) float hf[2 * 16 * EL_HP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int dir = blockIdx.y, s0 = blockIdx.x * 16;
+    const int unit = wave * 16 + l15;
+    const int rl = tid >> 4, q = tid & 15;
+    f16x8 wh[4][2], wl[4][2];
+    {
+        const _Float16* wp = w_pk + ((long)(dir * 4 + wave) * 8 * 64 + lane) * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                wh[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 2 + ks) * 64 * 16);
+                wl[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 2 + ks) * 64 * 16 + 8);
+            }
+    }
+    auto step_pos = [&](int it) -> int { it = min(max(it, 0), P - 1); return dir ? (P - 1 - it) : it; };
+    auto load_gx = [&](int it, float4 (&g)[4]) {           // this lane's (i,f,g,o) pre-activations of its 4 rows
+        const int p = step_pos(it);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = min(s0 + g4 * 4 + r, nseq - 1);
+            g[r] = *reinterpret_cast<const float4*>(&gx[((long)s * P + p) * 512 + dir * 256 + unit * 4]);
+        }
+    };
+    for (int i = tid; i < 16 * EL_AP; i += 256) { ahi[i] = (_Float16)0.f; alo[i] = (_Float16)0.f; }
+    for (int i = tid; i < 16 * EL_HP; i += 256) hf[i] = 0.f;
+    float creg[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 gxr[4];
+    load_gx(0, gxr);
+    __syncthreads();
+    constexpr float INV = 1.0f / ESPLIT;
+    for (int it = 0; it < P; ++it) {
+        const int cur = it & 1, nxt = cur ^ 1;
+        {   // flush h_{it-1} (clamped: at it = 0 zeros go to the row of step 0 and are overwritten a step later)
+            const int s = min(s0 + rl, nseq - 1);
+            *reinterpret_cast<float4*>(&h_out[((long)s * P + step_pos(it - 1)) * 128 + dir * 64 + q * 4]) =
+                *reinterpret_cast<const float4*>(&hf[(cur * 16 + rl) * EL_HP + q * 4]);
+        }
+        f32x4 am[4], ac[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            am[g] = f32x4{(&gxr[0].x)[g], (&gxr[1].x)[g], (&gxr[2].x)[g], (&gxr[3].x)[g]};
+            ac[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        load_gx(it + 1, gxr);
+        const int ro = (cur * 16 + l15) * EL_AP + g4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) am[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], am[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], ac[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], ac[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = sigmoid_f(am[0][r] + ac[0][r] * INV);
+            const float fg = sigmoid_f(am[1][r] + ac[1][r] * INV);
+            const float gg = tanh_f(am[2][r] + ac[2][r] * INV);
+            const float og = sigmoid_f(am[3][r] + ac[3][r] * INV);
+            const float cc = fg * creg[r] + ig * gg;
+            creg[r] = cc;
+            const float hv = og * tanh_f(cc);
+            const int row = g4 * 4 + r;
+            const _Float16 th = (_Float16)hv;
+            ahi[(nxt * 16 + row) * EL_AP + unit] = th;
+            alo[(nxt * 16 + row) * EL_AP + unit] = (_Float16)((hv - (float)th) * ESPLIT);
+            hf[(nxt * 16 + row) * EL_HP + unit] = hv;
+        }
+        __syncthreads();
+    }
+    if (s0 + rl < nseq)
+        *reinterpret_cast<float4*>(&h_out[((long)(s0 + rl) * P + step_pos(P - 1)) * 128 + dir * 64 + q * 4]) =
+            *reinterpret_cast<const float4*>(&hf[((P & 1) * 16 + rl) * EL_HP + q * 4]);
+}
+
+// out[r] = x[r] + b + sum_{k<4} Wt_k h[(s, q - k)]   (ConvTranspose1d(128 -> 64, 4, stride 1) + residual); 32-row tiles
+template <bool INTER>
+__global__ void __launch_bounds__(256, 2) k_emb_convt_res(const float* __restrict__ h, const _Float16* __restrict__ w_pk,
+                                                          const float* __restrict__ bias, const float* __restrict__ x,
+                                                          float* __restrict__ out, long rows, int P, int T) {
+    constexpr int RP = 32, KS = 16, CSP = C + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[KS * 4 * RP * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[KS * 4 * RP * 8];
+    __shared__ __attribute__((aligned(16))) float cs[RP * CSP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    f16x8 wh[KS], wl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const _Float16* p = w_pk + ((long)(wave * KS + ks) * 64 + lane) * 16;
+        wh[ks] = *reinterpret_cast<const f16x8*>(p);
+        wl[ks] = *reinterpret_cast<const f16x8*>(p + 8);
+    }
+    const float bz = bias[wave * 16 + l15];
+    const int ntiles = (int)((rows + RP - 1) / RP);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long r0 = (long)tile * RP;
+        __syncthreads();
+        // A row = [h(q) | h(q-1) | h(q-2) | h(q-3)], 128 floats each (zeros outside 0..P-1): 32 x 4 x 32 float4
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + 256 * (half * 8 + i);
+                const int rr = e >> 7, k = (e >> 5) & 3, c4 = e & 31;
+                const long r = min(r0 + rr, rows - 1);
+                int s, qq;
+                if (INTER) { const long bt = r / EF; s = (int)(bt / T) * EF + (int)(r % EF); qq = (int)(bt % T); }
+                else { s = (int)(r / EF); qq = (int)(r % EF); }
+                const int p = qq - k;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p >= 0 && p < P) v[i] = *reinterpret_cast<const float4*>(&h[((long)s * P + p) * 128 + c4 * 4]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + 256 * (half * 8 + i);
+                const int rr = e >> 7, k = (e >> 5) & 3, c4 = e & 31;
+                e_store_split4<RP>(ahi, alo, rr, k * 128 + c4 * 4, v[i].x, v[i].y, v[i].z, v[i].w);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < RP / 16; ++m) {
+            const f32x4 acc = e_mma<RP, KS>(ahi, alo, m, g4, l15, wh, wl, bz);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[(m * 16 + g4 * 4 + r) * CSP + wave * 16 + l15] = acc[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i, rr = e >> 4, c4 = e & 15;
+            const long r = r0 + rr;
+            if (r < rows) {
+                const float4 cv = *reinterpret_cast<const float4*>(&cs[rr * CSP + c4 * 4]);
+                const float4 xv = *reinterpret_cast<const float4*>(&x[r * C + c4 * 4]);
+                *reinterpret_cast<float4*>(&out[r * C + c4 * 4]) = make_float4(cv.x + xv.x, cv.y + xv.y, cv.z + xv.z, cv.w + xv.w);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention branch of the espnet2 GridNetBlock.  Frame kernels (one [65 x 64] frame per iteration, persistent):
+//   k_emb_qkv   per head h: Conv2d 1x1 (64 -> 8 | 8 | 16) + PReLU (own slope) + LayerNorm over (c, f) with [c][f]
+//               affine; written head-major [4B][T][d*65] with flat index f*d + c (the order is internal: Q.K is
+//               order-invariant and the V order is undone by the fused head merge of k_emb_attn)
+//   k_emb_proj  Conv2d 1x1 (64 -> 64) + PReLU + LayerNorm over (c, f) + residual
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int EFR_RP = 80;                       // 5 row tiles cover 65 bins
+constexpr int EFR_A = 2 * 4 * EFR_RP * 8;
+constexpr int EFR_NLD = (EF * 16 + 255) / 256;   // 5 float4 per thread
+constexpr int ENQKV = NH * (2 * EE + VD);        // 128 output columns: Q (h*8+e) | K | V (h*16+v)
+
+__device__ __forceinline__ void efr_load(const float* __restrict__ src, int tid, float4 (&stg)[EFR_NLD]) {
+#pragma unroll
+    for (int i = 0; i < EFR_NLD; ++i) {
+        const int e = min(tid + 256 * i, EF * 16 - 1);
+        stg[i] = *reinterpret_cast<const float4*>(&src[(e >> 4) * C + (e & 15) * 4]);
+    }
+}
+__device__ __forceinline__ void efr_store(_Float16* ahi, _Float16* alo, int tid, const float4 (&stg)[EFR_NLD]) {
+#pragma unroll
+    for (int i = 0; i < EFR_NLD; ++i) {
+        const int e = tid + 256 * i;
+        if (e < EF * 16) e_store_split4<EFR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[i].x, stg[i].y, stg[i].z, stg[i].w);
+    }
+}
+__device__ __forceinline__ void efr_zero_pad(_Float16* ahi, _Float16* alo, int tid) {
+    for (int e = tid; e < (EFR_RP - EF) * 16; e += 256) e_store_split4<EFR_RP>(ahi, alo, EF + (e >> 4), (e & 15) * 4, 0.f, 0.f, 0.f, 0.f);
+}
+
+// one wave: LayerNorm over ys[f][col0 + c], f < 65, c < D (flat index i = f*D + c), affine gw/gb indexed by i
+template <int D>
+__device__ __forceinline__ void e_ln_head(const float* ys, int yp, int col0, const float* __restrict__ gw,
+                                          const float* __restrict__ gb, float* __restrict__ dst, int lane) {
+    constexpr int N = EF * D, IT = (N + 63) / 64;
+    auto at = [&](int k) -> float { const int i = lane + 64 * k; return i < N ? ys[(i / D) * yp + col0 + (i % D)] : 0.f; };
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) s += at(k);
+    const float mean = wave_sum(s) * (1.0f / N);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) { const float dv = at(k) - mean; if (lane + 64 * k < N) v += dv * dv; }
+    const float rstd = rsqrtf(wave_sum(v) * (1.0f / N) + LN_EPS);
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = lane + 64 * k;
+        if (i < N) dst[i] = (at(k) - mean) * rstd * gw[i] + gb[i];
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_emb_qkv(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
+                                                    const float* __restrict__ bias, const float* __restrict__ slopes,
+                                                    const float* __restrict__ lnq_w, const float* __restrict__ lnq_b,
+                                                    const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
+                                                    const float* __restrict__ lnv_w, const float* __restrict__ lnv_b,
+                                                    float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
+                                                    int B, int T) {
+    constexpr int YP = ENQKV + 1;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[EFR_A];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[EFR_A];
+    __shared__ float ys[EF * YP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    f16x8 wh0[2], wl0[2], wh1[2], wl1[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const _Float16* p0 = w_pk + ((long)(wave * 2 + ks) * 64 + lane) * 16;
+        const _Float16* p1 = w_pk + ((long)((wave + 4) * 2 + ks) * 64 + lane) * 16;
+        wh0[ks] = *reinterpret_cast<const f16x8*>(p0); wl0[ks] = *reinterpret_cast<const f16x8*>(p0 + 8);
+        wh1[ks] = *reinterpret_cast<const f16x8*>(p1); wl1[ks] = *reinterpret_cast<const f16x8*>(p1 + 8);
+    }
+    const int c0 = wave * 16 + l15, c1 = c0 + 64;
+    const float bz0 = bias[c0], bz1 = bias[c1], a0 = slopes[c0], a1 = slopes[c1];
+    efr_zero_pad(ahi, alo, tid);
+    const int nframes = B * T;
+    float4 stg[EFR_NLD];
+    if ((int)blockIdx.x < nframes) efr_load(y + (long)blockIdx.x * EF * C, tid, stg);
+    for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {
+        const int b = fr / T, t = fr % T;
+        efr_store(ahi, alo, tid, stg);
+        __syncthreads();
+        if (fr + (int)gridDim.x < nframes) efr_load(y + (long)(fr + gridDim.x) * EF * C, tid, stg);
+#pragma unroll 1
+        for (int m = 0; m < EFR_RP / 16; ++m) {
+            const f32x4 r0 = e_mma<EFR_RP, 2>(ahi, alo, m, g4, l15, wh0, wl0, bz0);
+            const f32x4 r1 = e_mma<EFR_RP, 2>(ahi, alo, m, g4, l15, wh1, wl1, bz1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + g4 * 4 + r;
+                if (row < EF) { ys[row * YP + c0] = prelu_f(r0[r], a0); ys[row * YP + c1] = prelu_f(r1[r], a1); }
+            }
+        }
+        __syncthreads();
+        const int hd = wave, ln = lane + (fr >> 30);          // (fr >> 30) = 0: blocks LICM of the slot addresses
+        const long row = ((long)hd * B + b) * T + t;           // head-major batch order [nh*B] like espnet2's torch.cat
+        e_ln_head<EE>(ys, YP, hd * EE, lnq_w + hd * EDQK, lnq_b + hd * EDQK, q + row * EDQK, ln);
+        e_ln_head<EE>(ys, YP, NH * EE + hd * EE, lnk_w + hd * EDQK, lnk_b + hd * EDQK, k + row * EDQK, ln);
+        e_ln_head<VD>(ys, YP, 2 * NH * EE + hd * VD, lnv_w + hd * EDV, lnv_b + hd * EDV, v + row * EDV, ln);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_emb_proj(const float* __restrict__ merged, const _Float16* __restrict__ w_pk,
+                                                     const float* __restrict__ bias, const float* __restrict__ slope,
+                                                     const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                     const float* __restrict__ y2, float* __restrict__ out, int nframes) {
+    constexpr int YP = C + 4, N = EF * C, N4 = N / 4, NSLOT = (N4 + 255) / 256;     // 1040 float4 -> 5 slots
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[EFR_A];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[EFR_A];
+    __shared__ __attribute__((aligned(16))) float ys[EF * YP];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    f16x8 wh[2], wl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const _Float16* p = w_pk + ((long)(wave * 2 + ks) * 64 + lane) * 16;
+        wh[ks] = *reinterpret_cast<const f16x8*>(p); wl[ks] = *reinterpret_cast<const f16x8*>(p + 8);
+    }
+    const float bz = bias[wave * 16 + l15], a = slope[0];
+    float4 pw[NSLOT], pb[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        const int i = min(tid + 256 * k, N4 - 1);
+        pw[k] = *reinterpret_cast<const float4*>(&lnw[i * 4]);
+        pb[k] = *reinterpret_cast<const float4*>(&lnb[i * 4]);
+    }
+    efr_zero_pad(ahi, alo, tid);
+    float4 stg[EFR_NLD];
+    if ((int)blockIdx.x < nframes) efr_load(merged + (long)blockIdx.x * N, tid, stg);
+    for (int fidx = blockIdx.x; fidx < nframes; fidx += gridDim.x) {
+        const long fr = (long)fidx * N;
+        efr_store(ahi, alo, tid, stg);
+        __syncthreads();
+        if (fidx + (int)gridDim.x < nframes) efr_load(merged + (long)(fidx + gridDim.x) * N, tid, stg);
+        float4 rv[NSLOT];
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) rv[k] = *reinterpret_cast<const float4*>(&y2[fr + (long)min(tid + 256 * k, N4 - 1) * 4]);
+#pragma unroll 1
+        for (int m = 0; m < EFR_RP / 16; ++m) {
+            const f32x4 acc = e_mma<EFR_RP, 2>(ahi, alo, m, g4, l15, wh, wl, bz);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + g4 * 4 + r;
+                if (row < EF) ys[row * YP + wave * 16 + l15] = prelu_f(acc[r], a);
+            }
+        }
+        __syncthreads();
+        float4 vv[NSLOT];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const int i = min(tid + 256 * k, N4 - 1);
+            vv[k] = *reinterpret_cast<const float4*>(&ys[(i >> 4) * YP + (i & 15) * 4]);
+            if (tid + 256 * k < N4) s += vv[k].x + vv[k].y + vv[k].z + vv[k].w;
+        }
+        const float mean = block_sum_256(s, red) * (1.0f / N);
+        float vs = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const float dx = vv[k].x - mean, dy = vv[k].y - mean, dz = vv[k].z - mean, dw = vv[k].w - mean;
+            if (tid + 256 * k < N4) vs += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+        const float rstd = rsqrtf(block_sum_256(vs, red) * (1.0f / N) + LN_EPS);
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < N4) {
+                float4 o;
+                o.x = rv[k].x + (vv[k].x - mean) * rstd * pw[k].x + pb[k].x;
+                o.y = rv[k].y + (vv[k].y - mean) * rstd * pw[k].y + pb[k].y;
+                o.z = rv[k].z + (vv[k].z - mean) * rstd * pw[k].z + pb[k].z;
+                o.w = rv[k].w + (vv[k].w - mean) * rstd * pw[k].w + pb[k].w;
+                *reinterpret_cast<float4*>(&out[fr + i * 4]) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Full attention over all T frames (no mask), one (head, batch) row group x 16 queries per workgroup, keys in tiles
+// of 64 with an online softmax; exact fp32 MFMA.  Q fragments of the workgroup's queries stay in registers, score
+// tiles are reduced over the feature axis through LDS (each wave owns a slice of d), P.V streams V rows as float4
+// row segments (4 MFMA column tiles per load) and the head merge is fused into the final store:
+//   merged[b][t][f][h*16 + v] = O[h*B + b][t][f*16 + v] / l
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int EA_TQ = 16, EA_TK = 64;
+constexpr int EA_F4 = EDQK / 4;                  // 130 float4 per q/k row
+constexpr int EA_IT = (EA_F4 + 15) / 16;         // 9 feature iterations (16 float4 slots per iteration: 4 waves x 4 groups)
+constexpr int EA_CG = (EDV + 63) / 64;           // 17 column groups of 64 V columns (last one: 16 columns)
+constexpr int EA_MAXCG = (EA_CG + 3) / 4;        // 5 per wave
+
+__global__ void __launch_bounds__(256, 2) k_emb_attn(const float* __restrict__ q, const float* __restrict__ k,
+                                                     const float* __restrict__ v, float* __restrict__ merged, int B, int T,
+                                                     int ntq) {
+    __shared__ float sp[4][EA_TQ][EA_TK + 1];
+    __shared__ float pm[EA_TQ][EA_TK + 4];
+    __shared__ float mrow[EA_TQ], lrow[EA_TQ], frow[EA_TQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int bh = blockIdx.x / ntq, t0 = (blockIdx.x % ntq) * EA_TQ;        // bh = h*B + b
+    const float* qb = q + (long)bh * T * EDQK;
+    const float* kb = k + (long)bh * T * EDQK;
+    const float* vb = v + (long)bh * T * EDV;
+    const float scale = 1.0f / sqrtf((float)EDQK);
+
+    // this lane's Q fragments: query row l15, feature float4 slots it*16 + wave*4 + g4
+    float4 qf[EA_IT];
+    {
+        const float* qrow = qb + (long)min(t0 + l15, T - 1) * EDQK;
+#pragma unroll
+        for (int it = 0; it < EA_IT; ++it) {
+            const int f4 = it * 16 + wave * 4 + g4;
+            qf[it] = f4 < EA_F4 ? *reinterpret_cast<const float4*>(qrow + f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (tid < EA_TQ) { mrow[tid] = -3.0e38f; lrow[tid] = 0.f; frow[tid] = 1.f; }
+    f32x4 oacc[EA_MAXCG][4];
+#pragma unroll
+    for (int c = 0; c < EA_MAXCG; ++c)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) oacc[c][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < T; k0 += EA_TK) {
+        // ---- scores of 16 queries x 64 keys, partial over this wave's feature slice
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < EA_IT; ++it) {
+            const int f4 = it * 16 + wave * 4 + g4;
+            const bool ok = f4 < EA_F4;
+            const float av[4] = {qf[it].x, qf[it].y, qf[it].z, qf[it].w};
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float* krow = kb + (long)min(k0 + nt * 16 + l15, T - 1) * EDQK;
+                float4 b4 = *reinterpret_cast<const float4*>(krow + (ok ? f4 * 4 : 0));
+                if (!ok) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                              // previous tile's pm / frow consumed
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[wave][g4 * 4 + r][nt * 16 + l15] = acc[nt][r];
+        __syncthreads();
+
+        // ---- online softmax: 16 threads per query, 4 keys each
+        {
+            const int i = tid >> 4, sub = tid & 15;
+            float sv[4], mx = -3.0e38f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = sub + 16 * u;
+                float sc = -3.0e38f;
+                if (k0 + n < T) sc = (sp[0][i][n] + sp[1][i][n] + sp[2][i][n] + sp[3][i][n]) * scale;
+                sv[u] = sc;
+                mx = fmaxf(mx, sc);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float mold = mrow[i], mnew = fmaxf(mold, mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = sub + 16 * u;
+                const float pv = (k0 + n < T) ? __expf(sv[u] - mnew) : 0.f;
+                pm[i][n] = pv;
+                sum += pv;
+            }
+            sum = group16_sum(sum);
+            const float fac = __expf(mold - mnew);
+            __syncthreads();                          // every thread has read mrow/lrow of the previous tile
+            if (sub == 0) { mrow[i] = mnew; lrow[i] = lrow[i] * fac + sum; frow[i] = fac; }
+        }
+        __syncthreads();
+
+        // ---- O = O * fac + P V
+        float fr4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fr4[r] = frow[g4 * 4 + r];
+        float pa[EA_TK / 4];
+#pragma unroll
+        for (int ks = 0; ks < EA_TK / 4; ++ks) pa[ks] = pm[l15][ks * 4 + g4];
+#pragma unroll
+        for (int c = 0; c < EA_MAXCG; ++c) {
+            const int cg = wave + 4 * c;
+            if (cg < EA_CG) {                         // wave-uniform
+                const int col = cg * 64 + l15 * 4;
+                const int lcol = col < EDV ? col : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[c][u][r] *= fr4[r];
+#pragma unroll
+                for (int ks = 0; ks < EA_TK / 4; ++ks) {
+                    const int row = min(k0 + ks * 4 + g4, T - 1);
+                    const float4 v4 = *reinterpret_cast<const float4*>(vb + (long)row * EDV + lcol);
+                    oacc[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.x, oacc[c][0], 0, 0, 0);
+                    oacc[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.y, oacc[c][1], 0, 0, 0);
+                    oacc[c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.z, oacc[c][2], 0, 0, 0);
+                    oacc[c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.w, oacc[c][3], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- normalise and store with the head merge fused: V column = f*16 + vv
+    const int hd = bh / B, b = bh % B;
+    float inv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv[r] = 1.0f / lrow[g4 * 4 + r];
+#pragma unroll
+    for (int c = 0; c < EA_MAXCG; ++c) {
+        const int cg = wave + 4 * c;
+        const int col = cg * 64 + l15 * 4;
+        if (cg < EA_CG && col < EDV) {
+            const int f = col >> 4, vv = col & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + g4 * 4 + r;
+                if (t < T)
+                    *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * EF + f) * C + hd * VD + vv]) =
+                        make_float4(oacc[c][0][r] * inv[r], oacc[c][1][r] * inv[r], oacc[c][2][r] * inv[r], oacc[c][3][r] * inv[r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Embedding head (tfgridnet_orig/tfgridnet.py:120-127): Linear(65*64 -> 256) on every frame, LayerNorm(256), mean
+// over frames.  One workgroup = 64 frames of one utterance x all 256 outputs (8 waves x 2 column tiles x 4 row
+// tiles), K = 4160 streamed in 64-wide chunks through a split-precision LDS image; the per-tile frame sums go to
+// `part` and k_emb_head_mean adds them in a fixed order (bit-reproducible, no atomics).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int EH_K = EF * C;          // 4160, flat (f*64 + c) — the weight image is packed in that order
+constexpr int EH_KS = EH_K / 32;      // 130
+constexpr int EH_N = 256;
+constexpr int EH_ROWS = 64;
+
+__global__ void __launch_bounds__(512, 1) k_emb_head(const float* __restrict__ z, const _Float16* __restrict__ w_pk,
+                                                     const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                     const float* __restrict__ lnb, float* __restrict__ part, int T, int ntile) {
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * 4 * EH_ROWS * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * 4 * EH_ROWS * 8];
+    __shared__ float rs[8][EH_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.y, t0 = blockIdx.x * EH_ROWS;
+    const float* zb = z + (long)b * T * EH_K;
+
+    f32x4 am[4][2], ac[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float bz = bias[wave * 32 + nt * 16 + l15];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { am[mt][nt] = f32x4{bz, bz, bz, bz}; ac[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const int r0 = tid >> 4, k4 = (tid & 15) * 4;                 // staging: rows r0 and r0 + 32, 4 features at k4
+    const float* src0 = zb + (long)min(t0 + r0, T - 1) * EH_K + k4;
+    const float* src1 = zb + (long)min(t0 + r0 + 32, T - 1) * EH_K + k4;
+    float4 s0 = *reinterpret_cast<const float4*>(src0), s1 = *reinterpret_cast<const float4*>(src1);
+#pragma unroll 1
+    for (int kc = 0; kc < EH_KS / 2; ++kc) {
+        __syncthreads();
+        e_store_split4<EH_ROWS>(ahi, alo, r0, k4, s0.x, s0.y, s0.z, s0.w);
+        e_store_split4<EH_ROWS>(ahi, alo, r0 + 32, k4, s1.x, s1.y, s1.z, s1.w);
+        __syncthreads();
+        if (kc + 1 < EH_KS / 2) {
+            s0 = *reinterpret_cast<const float4*>(src0 + (kc + 1) * 64);
+            s1 = *reinterpret_cast<const float4*>(src1 + (kc + 1) * 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 wh[2], wl[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const _Float16* p = w_pk + (((long)(wave * 2 + nt) * EH_KS + kc * 2 + ks) * 64 + lane) * 16;
+                wh[nt] = *reinterpret_cast<const f16x8*>(p);
+                wl[nt] = *reinterpret_cast<const f16x8*>(p + 8);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int idx = e_slot<EH_ROWS>(ks * 4 + g4, mt * 16 + l15);
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    am[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[nt], am[mt][nt], 0, 0, 0);
+                    ac[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[nt], ac[mt][nt], 0, 0, 0);
+                    ac[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[nt], ac[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- LayerNorm(256) per frame (two-pass), then the sum over this tile's valid frames
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) am[mt][nt] = am[mt][nt] + ac[mt][nt] * (1.0f / ESPLIT);
+    float mean[4][4], rstd[4][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v;
+                if (pass == 0) v = am[mt][0][r] + am[mt][1][r];
+                else { const float d0 = am[mt][0][r] - mean[mt][r], d1 = am[mt][1][r] - mean[mt][r]; v = d0 * d0 + d1 * d1; }
+                v = group16_sum(v);
+                if (l15 == 0) rs[wave][mt * 16 + g4 * 4 + r] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mt * 16 + g4 * 4 + r;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += rs[w][row];
+                if (pass == 0) mean[mt][r] = v * (1.0f / EH_N);
+                else rstd[mt][r] = rsqrtf(v * (1.0f / EH_N) + LN_EPS);
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = wave * 32 + nt * 16 + l15;
+        const float gw = lnw[col], gb = lnb[col];
+        float sum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (t0 + mt * 16 + g4 * 4 + r < T) sum += (am[mt][nt][r] - mean[mt][r]) * rstd[mt][r] * gw + gb;
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (g4 == 0) part[((long)b * ntile + blockIdx.x) * EH_N + col] = sum;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_emb_head_mean(const float* __restrict__ part, float* __restrict__ out, int T, int ntile) {
+    const int b = blockIdx.x, col = threadIdx.x;
+    float s = 0.f;
+    for (int i = 0; i < ntile; ++i) s += part[((long)b * ntile + i) * EH_N + col];
+    out[(long)b * EH_N + col] = s / (float)T;
+}
+
+}  // namespace lh
+
+extern "C" int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_pk, const float* wconv_pk,
+                               const float* bconv, const float* gn_w, const float* gn_b, double* gn_part, float* z,
+                               int B, int T, int n_samples, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !inv_std || !wfb_pk || !wconv_pk || !bconv || !gn_w || !gn_b || !gn_part || !z || B <= 0 || T <= 0)
+        return LH_ERR_ARG;
+    if (T != n_samples / EHOP + 1 || n_samples < ENFFT) return LH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_emb_std, dim3(B), dim3(256), 0, st, x, inv_std, NMIC * n_samples);
+    const int tiles = B * ((T + EM_TT - 1) / EM_TT);
+    hipLaunchKernelGGL(k_emb_stft_conv, dim3(tiles < 256 ? tiles : 256), dim3(256), 0, st, x, inv_std, wfb_pk, wconv_pk,
+                       bconv, z, gn_part, B, T, n_samples);
+    hipLaunchKernelGGL(k_emb_gn_apply, dim3(64, B), dim3(256), 0, st, z, gn_part, gn_w, gn_b, T);
+    return check_launch();
+}
+
+// One axis path of a GridNetBlock: inter = 0 along frequency (sequences = frames), 1 along time (sequences = bins).
+//   x, out [B][T][65][64] (must not alias); wih_pk fp16 hi/lo image [32 ntiles][8 ksteps][64][16] of the folded,
+//   column-permuted input weights of both directions; bih [512]; whh_pk [2][4][4][2][64][16]; wct_pk [4][16][64][16]
+//   (ConvTranspose1d taps as [64 out] x [4*128]); bct [64]; gx scratch [nseq*P][512]; hbuf scratch [nseq*P][128]
+extern "C" int lh_emb_axis(const float* x, const void* wih_pk, const float* bih, const void* whh_pk, const void* wct_pk,
+                           const float* bct, float* gx, float* hbuf, float* out, int B, int T, int inter,
+                           lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !wih_pk || !bih || !whh_pk || !wct_pk || !bct || !gx || !hbuf || !out || B <= 0 || T < EKS || x == out)
+        return LH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nseq = inter ? B * EF : B * T;
+    const int P = (inter ? T : EF) - (EKS - 1);
+    const long grows = (long)nseq * P;
+    const int gtiles = (int)((grows + 63) / 64);
+    const long rows = (long)B * T * EF;
+    const int ctiles = (int)((rows + 31) / 32);
+    if (inter) {
+        hipLaunchKernelGGL((k_emb_gx<true>), dim3(gtiles < 64 ? gtiles : 64, 4), dim3(256), 0, st, x, (const _Float16*)wih_pk,
+                           bih, gx, nseq, P, T);
+        hipLaunchKernelGGL(k_emb_lstm, dim3((nseq + 15) / 16, 2), dim3(256), 0, st, gx, (const _Float16*)whh_pk, hbuf, nseq, P);
+        hipLaunchKernelGGL((k_emb_convt_res<true>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, hbuf,
+                           (const _Float16*)wct_pk, bct, x, out, rows, P, T);
+    } else {
+        hipLaunchKernelGGL((k_emb_gx<false>), dim3(gtiles < 64 ? gtiles : 64, 4), dim3(256), 0, st, x, (const _Float16*)wih_pk,
+                           bih, gx, nseq, P, T);
+        hipLaunchKernelGGL(k_emb_lstm, dim3((nseq + 15) / 16, 2), dim3(256), 0, st, gx, (const _Float16*)whh_pk, hbuf, nseq, P);
+        hipLaunchKernelGGL((k_emb_convt_res<false>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, hbuf,
+                           (const _Float16*)wct_pk, bct, x, out, rows, P, T);
+    }
+    return check_launch();
+}
+
+// Attention branch of one GridNetBlock: Q/K/V frame kernel, full attention, projection + LayerNorm + residual.
+//   y2, out [B][T][65][64]; merged scratch [B][T][65][64]; q, k scratch [4B][T][520]; v scratch [4B][T][1040];
+//   wqkv_pk fp16 hi/lo image [8][2][64][16] of the stacked 1x1-conv weights [128 x 64]; bqkv, slopes [128];
+//   lnq/lnk [4][520], lnv [4][1040] affine in flat (f*d + c) order; wproj_pk [4][2][64][16]; bproj [64]; slope_p [1];
+//   lnp_w/b [4160] in flat (f*64 + c) order
+extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const float* bqkv, const float* slopes,
+                                 const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                                 const float* lnv_w, const float* lnv_b, const void* wproj_pk, const float* bproj,
+                                 const float* slope_p, const float* lnp_w, const float* lnp_b, float* q, float* k, float* v,
+                                 float* merged, float* out, int B, int T, lh_stream_t stream) {
+    using namespace lh;
+    if (!y2 || !wqkv_pk || !bqkv || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !wproj_pk ||
+        !bproj || !slope_p || !lnp_w || !lnp_b || !q || !k || !v || !merged || !out || B <= 0 || T <= 0)
+        return LH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nframes = B * T;
+    hipLaunchKernelGGL(k_emb_qkv, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, st, y2, (const _Float16*)wqkv_pk, bqkv,
+                       slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, q, k, v, B, T);
+    const int ntq = (T + EA_TQ - 1) / EA_TQ;
+    hipLaunchKernelGGL(k_emb_attn, dim3(NH * B * ntq), dim3(256), 0, st, q, k, v, merged, B, T, ntq);
+    hipLaunchKernelGGL(k_emb_proj, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, st, merged, (const _Float16*)wproj_pk,
+                       bproj, slope_p, lnp_w, lnp_b, y2, out, nframes);
+    return check_launch();
+}
+
+// Embedding head: z [B][T][65][64] -> emb [B][256].  w_pk: fp16 hi/lo image [16][130][64][16] of the Linear weight
+// with its input features reordered to (f*64 + c); part: scratch [B][ceil(T/64)][256].
+extern "C" int lh_emb_head(const float* z, const void* w_pk, const float* bias, const float* ln_w, const float* ln_b,
+                           float* part, float* emb, int B, int T, lh_stream_t stream) {
+    using namespace lh;
+    if (!z || !w_pk || !bias || !ln_w || !ln_b || !part || !emb || B <= 0 || T <= 0) return LH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int ntile = (T + EH_ROWS - 1) / EH_ROWS;
+    hipLaunchKernelGGL(k_emb_head, dim3(ntile, B), dim3(512), 0, st, z, (const _Float16*)w_pk, bias, ln_w, ln_b, part, T, ntile);
+    hipLaunchKernelGGL(k_emb_head_mean, dim3(B), dim3(256), 0, st, part, emb, T, ntile);
+    return check_launch();
+}

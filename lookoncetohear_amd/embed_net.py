@@ -1,0 +1,248 @@
+"""`EmbedTFGridNet` — MI355X-native drop-in for the reference enrollment embedder
+`src.models.tfgridnet_orig.tfgridnet.EmbedTFGridNet` (configs/embed.json:4: `"model": "lookoncetohear_amd.embed_net.EmbedTFGridNet"`).
+
+Same constructor (`embed_dim, num_ch, n_fft, stride, num_blocks`, reference tfgridnet_orig/tfgridnet.py:89) and call
+(`forward(input [B, M, N]) -> [B, embed_dim]`, :100-127; used as `enroll_model.model(enrollments)` at
+src/ts_hear_test.py:129,134).  Parameter names follow the espnet2 `TFGridNet` module tree the reference subclasses
+(`conv.0/1`, `blocks.i.{intra,inter}_{norm,rnn,linear}`, `attn_conv_{Q,K,V}_h.{0,1,2}`, `attn_concat_proj`, `deconv`,
+plus the reference's own `embed_proj`), as restated in oracle/embedder_oracle.py — espnet2 itself is not available
+here, so that manifest is unverified against a real checkpoint (PARITY UNPINNED, see the oracle's header).
+
+Like `Net`, the torch modules are parameter containers; the arithmetic runs in HIP kernels (lh_embed.hip and the
+templated frame kernels of lh_pointwise.hip) behind the C ABI.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _cabi
+from .weights import pack_linear_f16x3, pack_mfma_f32, split_f16
+
+
+class _LN4D(nn.Module):
+    def __init__(self, shape):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(*shape))
+        self.beta = nn.Parameter(torch.zeros(*shape))
+
+
+def _head_conv(c_in, c_out, n_freqs):
+    return nn.Sequential(nn.Conv2d(c_in, c_out, 1), nn.PReLU(), _LN4D((1, c_out, 1, n_freqs)))
+
+
+class _EBlock(nn.Module):
+    def __init__(self, emb_dim, emb_ks, n_freqs, hidden, n_head):
+        super().__init__()
+        E = math.ceil(512 / n_freqs)
+        self.intra_norm = _LN4D((1, emb_dim, 1, 1))
+        self.intra_rnn = nn.LSTM(emb_dim * emb_ks, hidden, 1, batch_first=True, bidirectional=True)
+        self.intra_linear = nn.ConvTranspose1d(hidden * 2, emb_dim, emb_ks, stride=1)
+        self.inter_norm = _LN4D((1, emb_dim, 1, 1))
+        self.inter_rnn = nn.LSTM(emb_dim * emb_ks, hidden, 1, batch_first=True, bidirectional=True)
+        self.inter_linear = nn.ConvTranspose1d(hidden * 2, emb_dim, emb_ks, stride=1)
+        for h in range(n_head):
+            self.add_module(f"attn_conv_Q_{h}", _head_conv(emb_dim, E, n_freqs))
+            self.add_module(f"attn_conv_K_{h}", _head_conv(emb_dim, E, n_freqs))
+            self.add_module(f"attn_conv_V_{h}", _head_conv(emb_dim, emb_dim // n_head, n_freqs))
+        self.attn_concat_proj = _head_conv(emb_dim, emb_dim, n_freqs)
+
+
+def stft_rows(n_fft: int) -> torch.Tensor:
+    """[n_fft samples, n_fft + 2 rows]: periodic-hann-windowed DFT rows, cos (re) then -sin (im): torch.stft semantics."""
+    n = np.arange(n_fft, dtype=np.float64)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)
+    k = np.arange(n_fft // 2 + 1)
+    ang = 2.0 * np.pi * np.outer(n, k) / n_fft
+    return torch.from_numpy(np.concatenate([np.cos(ang), -np.sin(ang)], axis=1) * win[:, None]).float()
+
+
+class EmbedTFGridNet(nn.Module):
+    def __init__(self, embed_dim, num_ch, n_fft, stride, num_blocks):
+        super().__init__()
+        if (embed_dim, num_ch, n_fft, stride) != (256, 2, 128, 64):
+            raise NotImplementedError("the gfx950 embedder kernels are specialised on configs/embed.json "
+                                      f"(embed_dim 256, 2 mics, n_fft 128, stride 64); got {(embed_dim, num_ch, n_fft, stride)}")
+        self.embed_dim, self.n_imics, self.n_fft, self.stride, self.n_layers = embed_dim, num_ch, n_fft, stride, num_blocks
+        self.emb_dim, self.n_freqs, self.n_head, self.hidden, self.emb_ks = 64, n_fft // 2 + 1, 4, 64, 4
+        self.E = math.ceil(512 / self.n_freqs)
+        self.conv = nn.Sequential(nn.Conv2d(2 * num_ch, 64, (3, 3), padding=(1, 1)), nn.GroupNorm(1, 64, eps=1e-5))
+        self.blocks = nn.ModuleList([_EBlock(64, 4, self.n_freqs, 64, 4) for _ in range(num_blocks)])
+        self.deconv = nn.ConvTranspose2d(64, 2, (3, 3), padding=(1, 1))      # registered by the espnet2 trunk, unused here
+        self.embed_proj = nn.Sequential(nn.Linear(self.n_freqs * 64, embed_dim), nn.LayerNorm(embed_dim))
+        self._pack_key = None
+        self._packed = None
+        self._lib_override = None          # TEST HOOK ONLY (tests/hipemu)
+        self._debug_taps: Optional[dict] = None
+        self._prof: Optional[list] = None  # bench.py: (C-ABI call, start event, end event) per launch
+
+    # ------------------------------------------------------------------------------------------------
+    def _lib(self, t):
+        if self._lib_override is not None:
+            return self._lib_override
+        if not t.is_cuda:
+            raise RuntimeError("lookoncetohear_amd.EmbedTFGridNet runs on an MI355X (ROCm device tensors); there is no CPU path")
+        return _cabi.load()
+
+    def _weights(self, device) -> dict:
+        tensors = list(self.parameters())
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self._pack_key:
+            with torch.no_grad():
+                self._packed = pack_embedder({k: v.detach() for k, v in self.state_dict().items()}, self.n_layers)
+            self._pack_key = key
+        return self._packed
+
+    def forward(self, input):
+        lib = self._lib(input)
+        dev = input.device
+        x = input.contiguous().float()
+        B, M, N = x.shape
+        if M != self.n_imics:
+            raise ValueError(f"expected {self.n_imics} microphones, got {M}")
+        T = N // self.stride + 1
+        if T < self.emb_ks or N <= self.n_fft // 2:
+            raise ValueError(f"enrollment of {N} samples is too short: needs > {self.n_fft // 2} samples (reflect padding) "
+                             f"and >= {self.emb_ks} STFT frames (unfold kernel), like the reference")
+        F_, C_ = self.n_freqs, 64
+        with torch.no_grad():
+            pk = self._weights(dev)
+            st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
+            P = lambda t: t.data_ptr()
+            e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+            taps = self._debug_taps
+            prof = self._prof if x.is_cuda else None
+            if prof is not None:
+                lib_ = lib
+
+                class lib:                      # HIP events on the launch stream around each C-ABI call
+                    @staticmethod
+                    def call(name, *args):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        lib_.call(name, *args)
+                        e1.record()
+                        prof.append((name + ("" if name != "lh_emb_axis" else (".inter" if args[11] else ".intra")), e0, e1))
+            za, zb, zc = e(B, T, F_, C_), e(B, T, F_, C_), e(B, T, F_, C_)
+            inv_std = e(B)
+            tiles = B * ((T + 13) // 14)
+            gn_part = torch.empty(tiles * 2, device=dev, dtype=torch.float64)
+            lib.call("lh_emb_frontend", P(x), P(inv_std), P(pk["wfb"]), P(pk["conv_w"]), P(pk["conv_b"]), P(pk["gn_w"]),
+                     P(pk["gn_b"]), P(gn_part), P(za), B, T, N, st)
+            if taps is not None:
+                taps["z0"] = za.clone()
+            P_i, P_e = F_ - 3, T - 3
+            gx = e(max(B * T * P_i, B * F_ * P_e) * 512)
+            hbuf = e(max(B * T * P_i, B * F_ * P_e) * 128)
+            qb, kb = e(self.n_head * B * T * F_ * self.E), e(self.n_head * B * T * F_ * self.E)
+            vb = e(B * T * F_ * C_)
+            for i in range(self.n_layers):
+                bp = pk["blocks"][i]
+                lib.call("lh_emb_axis", P(za), P(bp["intra_wih"]), P(bp["intra_bih"]), P(bp["intra_whh"]), P(bp["intra_wct"]),
+                         P(bp["intra_bct"]), P(gx), P(hbuf), P(zb), B, T, 0, st)
+                lib.call("lh_emb_axis", P(zb), P(bp["inter_wih"]), P(bp["inter_bih"]), P(bp["inter_whh"]), P(bp["inter_wct"]),
+                         P(bp["inter_bct"]), P(gx), P(hbuf), P(zc), B, T, 1, st)
+                if taps is not None:
+                    taps[f"blocks.{i}.x1"], taps[f"blocks.{i}.x2"] = zb.clone(), zc.clone()
+                lib.call("lh_emb_attn_block", P(zc), P(bp["wqkv"]), P(bp["bqkv"]), P(bp["slopes"]), P(bp["lnq_w"]),
+                         P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(bp["wproj"]),
+                         P(bp["bproj"]), P(bp["slope_p"]), P(bp["lnp_w"]), P(bp["lnp_b"]), P(qb), P(kb), P(vb), P(zb), P(za),
+                         B, T, st)
+                if taps is not None:
+                    taps[f"blocks.{i}.O"], taps[f"blocks.{i}.out"] = zb.clone(), za.clone()
+            emb = e(B, self.embed_dim)
+            part = e(B * ((T + 63) // 64) * self.embed_dim)
+            lib.call("lh_emb_head", P(za), P(pk["head_w"]), P(pk["head_b"]), P(pk["head_ln_w"]), P(pk["head_ln_b"]), P(part),
+                     P(emb), B, T, st)
+            return emb
+
+
+def _pack_whh_f16x3(w_hh: torch.Tensor) -> torch.Tensor:
+    """[4 waves][4 gates][2 ksteps][64 lanes][hi|lo][8]: W_hh[g*64 + 16w + (l & 15)][ks*32 + (l >> 4)*8 + j]."""
+    dev = w_hh.device
+    lane = torch.arange(64, device=dev)
+    wave = torch.arange(4, device=dev)[:, None, None, None, None]
+    gate = torch.arange(4, device=dev)[None, :, None, None, None]
+    ks = torch.arange(2, device=dev)[None, None, :, None, None]
+    j = torch.arange(8, device=dev)[None, None, None, None, :]
+    col = gate * 64 + wave * 16 + (lane & 15)[None, None, None, :, None]
+    k = ks * 32 + (lane >> 4)[None, None, None, :, None] * 8 + j
+    hi, lo = split_f16(w_hh.float()[col, k])
+    return torch.stack([hi, lo], dim=4).contiguous()
+
+
+def _pack_axis(sd, pre, ax):
+    """Input GEMM of one axis path: both directions, LN affine folded, features reordered from espnet's unfold order
+    (c*4 + k) to window-major (k*64 + c), output columns reordered to (direction, unit, gate)."""
+    g = lambda k: sd[pre + k].double()
+    lw, lb = g(f"{ax}_norm.gamma").reshape(-1), g(f"{ax}_norm.beta").reshape(-1)
+    ws, bs = [], []
+    for sfx in ("", "_reverse"):
+        w = g(f"{ax}_rnn.weight_ih_l0{sfx}").reshape(256, 64, 4)                 # [col, c, k]
+        b = g(f"{ax}_rnn.bias_ih_l0{sfx}") + g(f"{ax}_rnn.bias_hh_l0{sfx}") + (w * lb[None, :, None]).sum((1, 2))
+        w = (w * lw[None, :, None]).permute(0, 2, 1).reshape(256, 256)           # [col, k*64 + c]
+        perm = (torch.arange(4, device=w.device)[None, :] * 64 + torch.arange(64, device=w.device)[:, None]).reshape(-1)  # new unit*4+gate <- gate*64+unit
+        ws.append(w[perm]); bs.append(b[perm])
+    out = {
+        f"{ax}_wih": pack_linear_f16x3(torch.cat(ws, 0).float()), f"{ax}_bih": torch.cat(bs).float().contiguous(),
+        f"{ax}_whh": torch.stack([_pack_whh_f16x3(sd[pre + f"{ax}_rnn.weight_hh_l0"]),
+                                  _pack_whh_f16x3(sd[pre + f"{ax}_rnn.weight_hh_l0_reverse"])]),
+        f"{ax}_wct": pack_linear_f16x3(sd[pre + f"{ax}_linear.weight"].permute(1, 2, 0).reshape(64, 512).float().contiguous()),
+        f"{ax}_bct": sd[pre + f"{ax}_linear.bias"].float().contiguous(),
+    }
+    return out
+
+
+def pack_embedder(sd: Dict[str, torch.Tensor], n_blocks: int) -> dict:
+    g = lambda k: sd[k]
+    dev = g("conv.0.weight").device
+    out = {
+        "wfb": pack_mfma_f32(stft_rows(128).to(dev)),                                   # [128, 130] -> [9][32][64]
+        "conv_w": pack_mfma_f32(g("conv.0.weight").reshape(64, 36).t()),                # [36, 64] -> [4][9][64]
+        "conv_b": g("conv.0.bias").float().contiguous(),
+        "gn_w": g("conv.1.weight").float().contiguous(), "gn_b": g("conv.1.bias").float().contiguous(),
+    }
+    out["blocks"] = []
+    for i in range(n_blocks):
+        pre = f"blocks.{i}."
+        bp = {}
+        bp.update(_pack_axis(sd, pre, "intra"))
+        bp.update(_pack_axis(sd, pre, "inter"))
+        bp.update(_pack_attn(sd, pre))
+        out["blocks"].append(bp)
+    # head: Linear input features (c*65 + f) -> (f*64 + c)
+    w = g("embed_proj.0.weight").float()
+    out["head_w"] = pack_linear_f16x3(w.reshape(-1, 64, 65).permute(0, 2, 1).reshape(w.shape[0], -1).contiguous())
+    out["head_b"] = g("embed_proj.0.bias").float().contiguous()
+    out["head_ln_w"], out["head_ln_b"] = g("embed_proj.1.weight").float().contiguous(), g("embed_proj.1.bias").float().contiguous()
+    return out
+
+
+def _pack_attn(sd, pre, n_head=4):
+    """Stacked Q|K|V head convs (columns Q h*8+e, K 32+h*8+e, V 64+h*16+v), per-column PReLU slopes, LayerNorm affines
+    re-ordered from [channel][bin] to (bin*d + channel)."""
+    g = lambda k: sd[pre + k].float()
+    ws, bs, sl, ln = [], [], [], {}
+    for nm in "QKV":
+        lw, lb = [], []
+        for h in range(n_head):
+            q = f"attn_conv_{nm}_{h}."
+            w = g(q + "0.weight")
+            d = w.shape[0]
+            ws.append(w.reshape(d, 64)); bs.append(g(q + "0.bias")); sl.append(g(q + "1.weight").reshape(1).expand(d))
+            lw.append(g(q + "2.gamma").reshape(d, -1).t().reshape(-1)); lb.append(g(q + "2.beta").reshape(d, -1).t().reshape(-1))
+        ln[nm] = (torch.stack(lw).contiguous(), torch.stack(lb).contiguous())
+    q = "attn_concat_proj."
+    return {
+        "wqkv": pack_linear_f16x3(torch.cat(ws, 0).contiguous()), "bqkv": torch.cat(bs).contiguous(),
+        "slopes": torch.cat(sl).contiguous(),
+        "lnq_w": ln["Q"][0], "lnq_b": ln["Q"][1], "lnk_w": ln["K"][0], "lnk_b": ln["K"][1], "lnv_w": ln["V"][0], "lnv_b": ln["V"][1],
+        "wproj": pack_linear_f16x3(g(q + "0.weight").reshape(64, 64).contiguous()), "bproj": g(q + "0.bias").contiguous(),
+        "slope_p": g(q + "1.weight").reshape(1).contiguous(),
+        "lnp_w": g(q + "2.gamma").reshape(64, -1).t().reshape(-1).contiguous(),
+        "lnp_b": g(q + "2.beta").reshape(64, -1).t().reshape(-1).contiguous(),
+    }

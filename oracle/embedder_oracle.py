@@ -132,15 +132,19 @@ def _axis_path(cfg, p, pre, ax, x):
                                stride=cfg.hs)                              # [N, C, L]
 
 
-def block(cfg: ECfg, p: dict, pre: str, x):
+def block(cfg: ECfg, p: dict, pre: str, x, taps=None):
     B, C, T, Q = x.shape
     assert (T - cfg.ks) % cfg.hs == 0 and (Q - cfg.ks) % cfg.hs == 0       # hs = 1: no padding branch
     y = _ln4d(x, p[pre + "intra_norm.gamma"], p[pre + "intra_norm.beta"], cfg.eps)
     y = _axis_path(cfg, p, pre, "intra", y.transpose(1, 2).reshape(B * T, C, Q)).view(B, T, C, Q).transpose(1, 2)
     x1 = y + x
+    if taps is not None:
+        taps[pre + 'x1'] = x1.permute(0, 2, 3, 1)
     y = _ln4d(x1, p[pre + "inter_norm.gamma"], p[pre + "inter_norm.beta"], cfg.eps)
     y = _axis_path(cfg, p, pre, "inter", y.permute(0, 3, 1, 2).reshape(B * Q, C, T)).view(B, Q, C, T).permute(0, 2, 3, 1)
     x2 = y + x1
+    if taps is not None:
+        taps[pre + 'x2'] = x2.permute(0, 2, 3, 1)
 
     def head(nm, h):
         q = pre + f"attn_conv_{nm}_{h}."
@@ -156,12 +160,15 @@ def block(cfg: ECfg, p: dict, pre: str, x):
     att = torch.softmax(Qf @ Kf.transpose(1, 2) / math.sqrt(Qf.shape[-1]), dim=2)     # full T x T, no mask
     O = (att @ Vt.flatten(2)).reshape(Vt.shape).transpose(1, 2)            # [nh*B, Vd, T, F]
     O = O.view(cfg.nh, B, cfg.Vd, T, Q).transpose(0, 1).reshape(B, cfg.nh * cfg.Vd, T, Q)
+    if taps is not None:
+        taps[pre + 'Q'], taps[pre + 'K'], taps[pre + 'V'] = Qh, Kh, Vh        # [nh*B, d, T, F], head-major batch
+        taps[pre + 'O'] = O.permute(0, 2, 3, 1)                               # [B, T, F, 64]
     q = pre + "attn_concat_proj."
     z = _prelu(TF.conv2d(O, p[q + "0.weight"], p[q + "0.bias"]), p[q + "1.weight"])
     return _ln4dcf(z, p[q + "2.gamma"], p[q + "2.beta"], cfg.eps) + x2
 
 
-def forward(cfg: ECfg, sd: dict, x, dtype=torch.float32):
+def forward(cfg: ECfg, sd: dict, x, dtype=torch.float32, taps=None):
     """EmbedTFGridNet.forward (tfgridnet_orig/tfgridnet.py:100-127): x [B, M, N] -> [B, embed_dim]."""
     p = {k: v.detach().to("cpu", dtype) for k, v in sd.items()}
     x = x.detach().to("cpu", dtype).transpose(1, 2)                        # [B, N, M]
@@ -173,9 +180,16 @@ def forward(cfg: ECfg, sd: dict, x, dtype=torch.float32):
     spec = spec.view(B, M, cfg.F, -1).permute(0, 1, 3, 2)                  # [B, M, T, F]
     z = torch.cat([spec.real, spec.imag], dim=1)                           # [B, 2M, T, F]
     z = TF.conv2d(z, p["conv.0.weight"], p["conv.0.bias"], padding=(1, 1))
+    if taps is not None:
+        taps['spec'] = torch.cat([spec.real, spec.imag], dim=1)
+        taps['zraw'] = z.permute(0, 2, 3, 1)
     z = TF.group_norm(z, 1, p["conv.1.weight"], p["conv.1.bias"], cfg.eps)
+    if taps is not None:
+        taps['z0'] = z.permute(0, 2, 3, 1)
     for i in range(cfg.nblk):
-        z = block(cfg, p, f"blocks.{i}.", z)
+        z = block(cfg, p, f"blocks.{i}.", z, taps)
+        if taps is not None:
+            taps[f'blocks.{i}.out'] = z.permute(0, 2, 3, 1)
     T = z.shape[2]
     e = z.permute(0, 2, 1, 3).reshape(B, T, cfg.C * cfg.F)                 # [B, T, C*F] (c-major)
     e = e @ p["embed_proj.0.weight"].t() + p["embed_proj.0.bias"]

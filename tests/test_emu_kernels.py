@@ -77,3 +77,32 @@ def test_cabi_argument_errors(emu_net):
     assert lib.raw("lh_check_config")(256, 128, 2, 64, 3, 64, 4, 50, 2, 256) == 2      # LH_ERR_UNSUPPORTED
     assert lib.raw("lh_local_attn")(None, None, None, None, 1, 1, None) == 1             # LH_ERR_ARG
     assert lib.raw("lh_linear_res")(None, None, None, None, None, 0, 64, None) == 1
+
+
+def test_embedder_stages_and_embedding():
+    """Enrollment embedder: every stage tap and the final embedding against oracle/embedder_oracle.py
+    (fp64) on 2 utterances x 21 frames — front end, both axis paths, Q/K/V + full attention + projection, head."""
+    from tests.hipemu.build_emu import build_emu
+    from lookoncetohear_amd.embed_net import EmbedTFGridNet
+    from oracle import embedder_oracle as E
+    cfg = E.ECfg(**E.EMBED_PARAMS)
+    sd = E.synthetic_state_dict(cfg, 0)
+    net = EmbedTFGridNet(**E.EMBED_PARAMS).eval()
+    net.load_state_dict(sd, strict=True)
+    net._lib_override = _cabi.Lib(build_emu())
+    x = synth.batch([0, 1], 1280)["mixture"]
+    taps, otaps = {}, {}
+    net._debug_taps = taps
+    emb = net(x)
+    net._debug_taps = None
+    ref = E.forward(cfg, sd, x, dtype=torch.float64, taps=otaps)
+    assert emb.shape == (2, 256)
+    for k, v in taps.items():
+        o = otaps[k].reshape(v.shape)
+        assert float((v.double() - o).abs().max()) < 1e-5 * float(o.abs().max()) + 1e-5, k
+    assert float((emb.double() - ref).abs().max()) < 2e-5
+    assert float(torch.nn.functional.cosine_similarity(emb.double(), ref).min()) > 1 - 1e-9
+    with pytest.raises(ValueError):
+        net(x[:, :, :100])                 # < 4 STFT frames
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 1280))       # wrong mic count

@@ -172,3 +172,43 @@ def test_edge_cases(net, oracle_cfg_sd):
         net(torch.zeros(1, 3, 1000, device=DEV), torch.zeros(1, 1, 256, device=DEV))    # wrong mic count
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 2, 1000), torch.zeros(1, 1, 256))                           # CPU tensors: no fallback
+
+
+# ---- enrollment embedder (SURVEY row a23 / BASELINE config 5).  The oracle is a restatement with PARITY UNPINNED
+# (espnet2 trunk absent from the reference tree, see oracle/embedder_oracle.py); these tests pin HIP == oracle.
+@pytest.fixture(scope="module")
+def embedder():
+    from lookoncetohear_amd.embed_net import EmbedTFGridNet
+    from oracle import embedder_oracle as E
+    _cabi.load()
+    cfg = E.ECfg(**E.EMBED_PARAMS)
+    sd = E.synthetic_state_dict(cfg, 0)
+    n = EmbedTFGridNet(**E.EMBED_PARAMS).eval()
+    n.load_state_dict(sd, strict=True)
+    return n.to(DEV), cfg, sd
+
+
+def test_embedder_matches_oracle(embedder):
+    from oracle import embedder_oracle as E
+    net_e, cfg, sd = embedder
+    for idx, n in (([0, 1, 2], 16000), ([3], 80000), ([4, 5], 1000)):       # 251, 1251 (full clip) and 16 frames
+        x = synth.batch(idx, n)["mixture"]
+        emb = net_e(x.to(DEV))
+        ref = E.forward(cfg, sd, x, dtype=torch.float64)
+        assert emb.shape == ref.shape == (len(idx), 256)
+        assert _err(emb, ref) < 5e-5, (n, _err(emb, ref))
+        cos = torch.nn.functional.cosine_similarity(emb.cpu().double(), ref)
+        assert float(cos.min()) > 1 - 1e-8
+
+
+def test_embedder_batch_invariance_and_determinism(embedder):
+    net_e, _, _ = embedder
+    x = synth.batch(list(range(6)), 32000)["mixture"].to(DEV)
+    a = net_e(x)
+    assert torch.equal(a, net_e(x))                                          # fixed reduction orders: bit-reproducible
+    b = torch.cat([net_e(x[i:i + 1]) for i in range(6)])
+    assert _err(a, b.cpu()) < 2e-5
+    with pytest.raises(RuntimeError):
+        net_e(torch.zeros(1, 2, 16000))                                      # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        net_e(torch.zeros(1, 2, 100, device=DEV))
