@@ -50,6 +50,10 @@ class Lib:
                 f"{path} not found: the HIP extension is not built. Run `python -m lookoncetohear_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
         self.path = path
+        # Import torch BEFORE dlopen: PyTorch-ROCm bundles its own libamdhip64.so, and the library must bind to the
+        # same HIP runtime that owns torch's streams and allocations.  Loaded first, it would pull in /opt/rocm's
+        # runtime as a second copy and every launch on a torch stream would fail (LH_ERR_LAUNCH).
+        import torch  # noqa: F401
         self._dll = ctypes.CDLL(path)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(self._dll, name)          # AttributeError here = missing export
