@@ -186,15 +186,20 @@ int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_pk, const f
  * ConvTranspose1d(128 -> 64, 4) -> + residual, as three launches (input GEMM over all windows, recurrence, gather-GEMM).
  *   x, out [B][T][65][64] (no alias); wih_pk fp16 hi/lo image [32][8][64][16] (both directions, LN affine folded,
  *   features window-major, columns (dir, unit, gate)); bih [512]; whh_pk [2][4][4][2][64][16]; wct_pk [4][16][64][16]
- *   of the taps as [64] x [4*128]; bct [64]; gx scratch [nseq*P][512]; hbuf scratch [nseq*P][128] (P = L - 3)
+ *   of the taps as [64] x [4*128]; bct [64]; xsplit scratch 2*B*T*65*64 fp16 (hi | lo images of the channel-
+ *   normalised input); gx scratch [nseq*P][512]; hbuf scratch [nseq*P][128] (P = L - 3)
  */
 int lh_emb_axis(const float* x, const void* wih_pk, const float* bih, const void* whh_pk, const void* wct_pk,
-                const float* bct, float* gx, float* hbuf, float* out, int B, int T, int inter, lh_stream_t stream);
+                const float* bct, void* xsplit, float* gx, float* hbuf, float* out, int B, int T, int inter,
+                lh_stream_t stream);
 
 /* Enrollment embedder, attention branch of one GridNetBlock (espnet2 GridNetBlock.forward attention part, restated in
  * oracle/embedder_oracle.py:149-168): per-head Q/K/V 1x1 conv + PReLU + LayerNorm over (channel, bin), full T x T
  * softmax attention per (head, utterance), head merge, attn_concat_proj (1x1 conv + PReLU + LayerNorm) + residual.
- *   y2, out  [B][T][65][64];  merged scratch [B][T][65][64];  q, k scratch [4B][T][520];  v scratch [4B][T][1040]
+ * Tp = T rounded up to a multiple of 64.
+ *   y2, out  [B][T][65][64];  merged scratch [B][T][65][64]
+ *   q, k     scratch fp16 [2][4B][T][544] (hi | lo images);  v scratch fp32 [4B][T][1040]
+ *   vt       scratch fp16 [2][4B][1040][Tp];  sc scratch fp32 [4B][T][Tp];  p scratch fp16 [2][4B][T][Tp]
  *   wqkv_pk  fp16 hi/lo image [8][2][64][16] of the stacked conv weights [128 x 64] (Q h*8+e | K | V h*16+v)
  *   bqkv, slopes [128] (PReLU slope of each output column's head conv)
  *   lnq_*, lnk_* [4][520], lnv_* [4][1040]: LayerNorm affine re-ordered to (bin*d + channel)
@@ -203,8 +208,8 @@ int lh_emb_axis(const float* x, const void* wih_pk, const float* bih, const void
 int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const float* bqkv, const float* slopes,
                       const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
                       const float* lnv_w, const float* lnv_b, const void* wproj_pk, const float* bproj,
-                      const float* slope_p, const float* lnp_w, const float* lnp_b, float* q, float* k, float* v,
-                      float* merged, float* out, int B, int T, lh_stream_t stream);
+                      const float* slope_p, const float* lnp_w, const float* lnp_b, void* q, void* k, float* v,
+                      void* vt, float* sc, void* p, float* merged, float* out, int B, int T, lh_stream_t stream);
 
 /* Enrollment embedder head (reference src/models/tfgridnet_orig/tfgridnet.py:120-127): Linear(65*64 -> 256) per
  * frame, LayerNorm(256), mean over frames.

@@ -11,7 +11,7 @@ from ctypes import c_int, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P, _I = c_void_p, c_int
 # name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
@@ -33,8 +33,8 @@ SIGNATURES = {
     "lh_proj_ln_res": [_P] * 9 + [_I, _I, _P],
     "lh_deconv_istft": [_P] * 9 + [_I, _I, _P],
     "lh_emb_frontend": [_P] * 9 + [_I, _I, _I, _P],
-    "lh_emb_axis": [_P] * 9 + [_I, _I, _I, _P],
-    "lh_emb_attn_block": [_P] * 20 + [_I, _I, _P],
+    "lh_emb_axis": [_P] * 10 + [_I, _I, _I, _P],
+    "lh_emb_attn_block": [_P] * 23 + [_I, _I, _P],
     "lh_emb_head": [_P] * 7 + [_I, _I, _P],
     "lh_metric_sums": [_P] * 8 + [_I, _I, _I, _P],
 }

@@ -2,7 +2,7 @@
 // espnet2 TF-GridNet trunk, see oracle/embedder_oracle.py): kernels that have no counterpart in the separator path.
 //   k_emb_std / k_emb_stft_conv / k_emb_gn_apply   std-normalise, STFT(128/64, hann, centred) + Conv2d 3x3 + GroupNorm
 //   k_emb_gx / k_emb_lstm / k_emb_convt_res        LN + unfold(4) input GEMM, BiLSTM recurrence, ConvTranspose1d + res
-//   k_emb_attn                                     full (T x T) attention with online softmax, head merge fused
+//   k_emb_vt / k_gemm_nt / k_emb_softmax           full (T x T) attention as two split-precision GEMMs, head merge fused
 //   k_emb_head / k_emb_head_mean                   Linear(65*64 -> 256) + LayerNorm + mean over frames
 // Activations are channel-last [B][T][65][64] like the separator's.
 #include "lh_common.h"
@@ -272,17 +272,51 @@ __device__ __forceinline__ long pos_row(int s, int pk, int T) {
     return (long)s * EF + pk;                                           // s = b*T + t,  pk = bin
 }
 
-// Gx[r][chunk*128 ..] = W_ih' unfold(standardise(x))[r] + b'   ; rows r = s*P + p ; grid (persistent, 4 column chunks)
+// channel LayerNorm (no affine: folded into the packed input weights) + fp16 hi/lo split of every position row, once
+// per axis call: xs = [hi image rows*64 halves | lo image rows*64 halves]; 16 lanes per 256-byte row
+__global__ void __launch_bounds__(256) k_emb_lnsplit(const float* __restrict__ x, _Float16* __restrict__ xs, long rows) {
+    const int tid = threadIdx.x, q = tid & 15;
+    _Float16* xh = xs;
+    _Float16* xl = xs + rows * C;
+    for (long r = (long)blockIdx.x * 16 + (tid >> 4); r < rows; r += (long)gridDim.x * 16) {
+        float4 u = *reinterpret_cast<const float4*>(&x[r * C + q * 4]);
+        const float mean = group16_sum(u.x + u.y + u.z + u.w) * (1.0f / C);
+        u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
+        const float var = group16_sum(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.0f / C);
+        const float rstd = rsqrtf(var + LN_EPS);
+        const float v[4] = {u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd};
+        f16x4 h4, l4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const _Float16 h = (_Float16)v[i];
+            h4[i] = h;
+            l4[i] = (_Float16)((v[i] - (float)h) * ESPLIT);
+        }
+        *reinterpret_cast<f16x4*>(&xh[r * C + q * 4]) = h4;
+        *reinterpret_cast<f16x4*>(&xl[r * C + q * 4]) = l4;
+    }
+}
+
+// Gx[s*P + p][chunk*128 ..] = W_ih' [xhat(s, p) | xhat(s, p+1) | xhat(s, p+2) | xhat(s, p+3)] + b'
+// One tile = 64 consecutive windows of ONE sequence: its 67 position rows are staged once (16-byte copies of the
+// pre-split images, no conversion) and the unfold is just a row offset in the A-fragment address (k-step ks covers
+// window element ks/2, channels 32*(ks&1)..+31).  grid (persistent, 4 column chunks of 128), weights in VGPRs.
+constexpr int GX_RP = 81;                         // odd row pitch (16-byte slots): conflict-free 16-byte staging writes
+constexpr int GX_ROWS = 64 + EKS - 1;             // 67 position rows per tile
+constexpr int GX_NLD = (GX_ROWS * 8 + 255) / 256; // 3 x 16 bytes per thread and image
+constexpr int GX_CSP = 132;
 template <bool INTER>
-__global__ void __launch_bounds__(256, 1) k_emb_gx(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
+__global__ void __launch_bounds__(256, 2) k_emb_gx(const _Float16* __restrict__ xs, const _Float16* __restrict__ w_pk,
                                                    const float* __restrict__ bias, float* __restrict__ gx, int nseq,
-                                                   int P, int T) {
-    constexpr int RP = 64, KS = 8, CSP = 132;
-    __shared__ __attribute__((aligned(16))) _Float16 ahi[KS * 4 * RP * 8];
-    __shared__ __attribute__((aligned(16))) _Float16 alo[KS * 4 * RP * 8];
-    __shared__ __attribute__((aligned(16))) float cs[RP * CSP];
+                                                   int P, int T, long rows_x) {
+    constexpr int KS = 8;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[8 * GX_RP * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[8 * GX_RP * 8];
+    __shared__ __attribute__((aligned(16))) float cs[64 * GX_CSP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
     const int chunk = blockIdx.y;
+    const _Float16* xh = xs;
+    const _Float16* xl = xs + rows_x * C;
     f16x8 wh[2][KS], wl[2][KS];
     float bz[2];
 #pragma unroll
@@ -296,50 +330,66 @@ __global__ void __launch_bounds__(256, 1) k_emb_gx(const float* __restrict__ x, 
         }
         bz[i] = bias[nt * 16 + l15];
     }
-    const long rows = (long)nseq * P;
-    const int ntiles = (int)((rows + RP - 1) / RP);
-    const int q = tid & 15;
+    const int L = P + EKS - 1;
+    const int tps = (P + 63) / 64;                       // tiles per sequence
+    const int ntiles = nseq * tps;
+    f16x8 sh[GX_NLD], sl[GX_NLD];
+    auto fetch = [&](int tile) {
+        const int s = tile / tps, p0 = (tile % tps) * 64;
+#pragma unroll
+        for (int i = 0; i < GX_NLD; ++i) {
+            const int e = min(tid + 256 * i, GX_ROWS * 8 - 1);
+            const long off = pos_row<INTER>(s, min(p0 + (e >> 3), L - 1), T) * C + (e & 7) * 8;
+            sh[i] = *reinterpret_cast<const f16x8*>(&xh[off]);
+            sl[i] = *reinterpret_cast<const f16x8*>(&xl[off]);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long r0 = (long)tile * RP;
-        __syncthreads();                                   // previous tile's cs reads done
-        // 64 rows x 4 window positions x 64 channels: 16 lanes per position row, LayerNorm over C fused
+        const int s = tile / tps, p0 = (tile % tps) * 64;
+        const int valid = min(64, P - p0);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int pr = ((tid + 256 * (half * 8 + i)) >> 4);          // 0..255 = row*4 + k
-                const long r = min(r0 + (pr >> 2), rows - 1);
-                const int s = (int)(r / P), p = (int)(r % P);
-                v[i] = *reinterpret_cast<const float4*>(&x[pos_row<INTER>(s, p + (pr & 3), T) * C + q * 4]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int pr = ((tid + 256 * (half * 8 + i)) >> 4);
-                float4 u = v[i];
-                const float mean = group16_sum(u.x + u.y + u.z + u.w) * (1.0f / C);
-                u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
-                const float var = group16_sum(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.0f / C);
-                const float rstd = rsqrtf(var + LN_EPS);
-                e_store_split4<RP>(ahi, alo, pr >> 2, (pr & 3) * C + q * 4, u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd);
+        for (int i = 0; i < GX_NLD; ++i) {
+            const int e = tid + 256 * i;
+            if (e < GX_ROWS * 8) {
+                const int idx = ((e & 7) * GX_RP + (e >> 3)) * 8;
+                *reinterpret_cast<f16x8*>(&ahi[idx]) = sh[i];
+                *reinterpret_cast<f16x8*>(&alo[idx]) = sl[i];
             }
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 #pragma unroll 1
-        for (int m = 0; m < RP / 16; ++m)
+        for (int m = 0; m < 4; ++m) {
+            f32x4 am[2], ac[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { am[i] = f32x4{bz[i], bz[i], bz[i], bz[i]}; ac[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int idx = (((ks & 1) * 4 + g4) * GX_RP + m * 16 + l15 + (ks >> 1)) * 8;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    am[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[i][ks], am[i], 0, 0, 0);
+                    ac[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[i][ks], ac[i], 0, 0, 0);
+                    ac[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[i][ks], ac[i], 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const f32x4 acc = e_mma<RP, KS>(ahi, alo, m, g4, l15, wh[i], wl[i], bz[i]);
+                const f32x4 acc = am[i] + ac[i] * (1.0f / ESPLIT);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cs[(m * 16 + g4 * 4 + r) * CSP + (wave * 2 + i) * 16 + l15] = acc[r];
+                for (int r = 0; r < 4; ++r) cs[(m * 16 + g4 * 4 + r) * GX_CSP + (wave * 2 + i) * 16 + l15] = acc[r];
             }
+        }
         __syncthreads();
+        float* dst = gx + ((long)s * P + p0) * 512 + chunk * 128;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i, rr = e >> 5, c4 = e & 31;
-            if (r0 + rr < rows)
-                *reinterpret_cast<float4*>(&gx[(r0 + rr) * 512 + chunk * 128 + c4 * 4]) =
-                    *reinterpret_cast<const float4*>(&cs[rr * CSP + c4 * 4]);
+            if (rr < valid)
+                *reinterpret_cast<float4*>(&dst[(long)rr * 512 + c4 * 4]) = *reinterpret_cast<const float4*>(&cs[rr * GX_CSP + c4 * 4]);
         }
     }
 }
@@ -548,14 +598,44 @@ __device__ __forceinline__ void e_ln_head(const float* ys, int yp, int col0, con
     }
 }
 
+// same LayerNorm, output as fp16 hi/lo rows of EQP halves (zero-padded past N) — the attention GEMM operand format
+constexpr int EQP = 544;                         // 520 features padded to 17 k-steps of 32
+template <int D>
+__device__ __forceinline__ void e_ln_head_split(const float* ys, int yp, int col0, const float* __restrict__ gw,
+                                                const float* __restrict__ gb, _Float16* __restrict__ dh,
+                                                _Float16* __restrict__ dl, int lane) {
+    constexpr int N = EF * D, IT = (EQP + 63) / 64;
+    static_assert(N <= EQP, "row pitch");
+    auto at = [&](int k) -> float { const int i = lane + 64 * k; return i < N ? ys[(i / D) * yp + col0 + (i % D)] : 0.f; };
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) s += at(k);
+    const float mean = wave_sum(s) * (1.0f / N);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) { const float dv = at(k) - mean; if (lane + 64 * k < N) v += dv * dv; }
+    const float rstd = rsqrtf(wave_sum(v) * (1.0f / N) + LN_EPS);
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EQP) {
+            const float o = i < N ? (at(k) - mean) * rstd * gw[i] + gb[i] : 0.f;
+            const _Float16 h = (_Float16)o;
+            dh[i] = h;
+            dl[i] = (_Float16)((o - (float)h) * ESPLIT);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256, 2) k_emb_qkv(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
                                                     const float* __restrict__ bias, const float* __restrict__ slopes,
                                                     const float* __restrict__ lnq_w, const float* __restrict__ lnq_b,
                                                     const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
                                                     const float* __restrict__ lnv_w, const float* __restrict__ lnv_b,
-                                                    float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
+                                                    _Float16* __restrict__ q, _Float16* __restrict__ k, float* __restrict__ v,
                                                     int B, int T) {
     constexpr int YP = ENQKV + 1;
+    const long img = (long)NH * B * T * EQP;              // q, k: [hi image | lo image], each [4B][T][544]
     __shared__ __attribute__((aligned(16))) _Float16 ahi[EFR_A];
     __shared__ __attribute__((aligned(16))) _Float16 alo[EFR_A];
     __shared__ float ys[EF * YP];
@@ -592,8 +672,8 @@ __global__ void __launch_bounds__(256, 2) k_emb_qkv(const float* __restrict__ y,
         __syncthreads();
         const int hd = wave, ln = lane + (fr >> 30);          // (fr >> 30) = 0: blocks LICM of the slot addresses
         const long row = ((long)hd * B + b) * T + t;           // head-major batch order [nh*B] like espnet2's torch.cat
-        e_ln_head<EE>(ys, YP, hd * EE, lnq_w + hd * EDQK, lnq_b + hd * EDQK, q + row * EDQK, ln);
-        e_ln_head<EE>(ys, YP, NH * EE + hd * EE, lnk_w + hd * EDQK, lnk_b + hd * EDQK, k + row * EDQK, ln);
+        e_ln_head_split<EE>(ys, YP, hd * EE, lnq_w + hd * EDQK, lnq_b + hd * EDQK, q + row * EQP, q + img + row * EQP, ln);
+        e_ln_head_split<EE>(ys, YP, NH * EE + hd * EE, lnk_w + hd * EDQK, lnk_b + hd * EDQK, k + row * EQP, k + img + row * EQP, ln);
         e_ln_head<VD>(ys, YP, 2 * NH * EE + hd * VD, lnv_w + hd * EDV, lnv_b + hd * EDV, v + row * EDV, ln);
     }
 }
@@ -675,154 +755,164 @@ __global__ void __launch_bounds__(256, 2) k_emb_proj(const float* __restrict__ m
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Full attention over all T frames (no mask), one (head, batch) row group x 16 queries per workgroup, keys in tiles
-// of 64 with an online softmax; exact fp32 MFMA.  Q fragments of the workgroup's queries stay in registers, score
-// tiles are reduced over the feature axis through LDS (each wave owns a slice of d), P.V streams V rows as float4
-// row segments (4 MFMA column tiles per load) and the head merge is fused into the final store:
-//   merged[b][t][f][h*16 + v] = O[h*B + b][t][f*16 + v] / l
+// Full attention over all T frames (no mask) as two batched split-precision GEMMs with the score matrix materialised
+// (T x T fp32 per (head, utterance) = 6.3 MB; with V rows of 1040 features a flash-style kernel cannot hold a
+// useful query tile of O in registers, and streaming K/V per 16 queries is L2-bound):
+//   k_emb_vt        V [T][1040] fp32 -> V^T hi/lo [1040][Tp] fp16 (keys contiguous = MFMA k axis), zero-padded keys
+//   k_gemm_nt<0>    S = Q K^T / sqrt(520)         A = Q hi/lo [T][544], B = K hi/lo [T][544]
+//   k_emb_softmax   P = softmax(S) rows as fp16 hi/lo [T][Tp], zero-padded keys
+//   k_gemm_nt<1>    O = P V, stored with the head merge fused: merged[b][t][f][h*16 + v] = O[h*B + b][t][f*16 + v]
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int EA_TQ = 16, EA_TK = 64;
-constexpr int EA_F4 = EDQK / 4;                  // 130 float4 per q/k row
-constexpr int EA_IT = (EA_F4 + 15) / 16;         // 9 feature iterations (16 float4 slots per iteration: 4 waves x 4 groups)
-constexpr int EA_CG = (EDV + 63) / 64;           // 17 column groups of 64 V columns (last one: 16 columns)
-constexpr int EA_MAXCG = (EA_CG + 3) / 4;        // 5 per wave
-
-__global__ void __launch_bounds__(256, 2) k_emb_attn(const float* __restrict__ q, const float* __restrict__ k,
-                                                     const float* __restrict__ v, float* __restrict__ merged, int B, int T,
-                                                     int ntq) {
-    __shared__ float sp[4][EA_TQ][EA_TK + 1];
-    __shared__ float pm[EA_TQ][EA_TK + 4];
-    __shared__ float mrow[EA_TQ], lrow[EA_TQ], frow[EA_TQ];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
-    const int bh = blockIdx.x / ntq, t0 = (blockIdx.x % ntq) * EA_TQ;        // bh = h*B + b
-    const float* qb = q + (long)bh * T * EDQK;
-    const float* kb = k + (long)bh * T * EDQK;
+__global__ void __launch_bounds__(256) k_emb_vt(const float* __restrict__ v, _Float16* __restrict__ vt, int T, int Tp,
+                                                long img) {
+    __shared__ float tl[64][65];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, bh = blockIdx.z;
     const float* vb = v + (long)bh * T * EDV;
-    const float scale = 1.0f / sqrtf((float)EDQK);
-
-    // this lane's Q fragments: query row l15, feature float4 slots it*16 + wave*4 + g4
-    float4 qf[EA_IT];
-    {
-        const float* qrow = qb + (long)min(t0 + l15, T - 1) * EDQK;
 #pragma unroll
-        for (int it = 0; it < EA_IT; ++it) {
-            const int f4 = it * 16 + wave * 4 + g4;
-            qf[it] = f4 < EA_F4 ? *reinterpret_cast<const float4*>(qrow + f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i, tt = e >> 6, cc = e & 63;
+        tl[tt][cc] = (t0 + tt < T && c0 + cc < EDV) ? vb[(long)(t0 + tt) * EDV + c0 + cc] : 0.f;
+    }
+    __syncthreads();
+    _Float16* oh = vt + (long)bh * EDV * Tp;
+    _Float16* ol = oh + img;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, cc = e >> 4, t4 = (e & 15) * 4;
+        if (c0 + cc < EDV) {
+            f16x4 h4, l4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = tl[t4 + j][cc];
+                const _Float16 h = (_Float16)x;
+                h4[j] = h;
+                l4[j] = (_Float16)((x - (float)h) * ESPLIT);
+            }
+            const long o = (long)(c0 + cc) * Tp + t0 + t4;
+            *reinterpret_cast<f16x4*>(&oh[o]) = h4;
+            *reinterpret_cast<f16x4*>(&ol[o]) = l4;
         }
     }
-    if (tid < EA_TQ) { mrow[tid] = -3.0e38f; lrow[tid] = 0.f; frow[tid] = 1.f; }
-    f32x4 oacc[EA_MAXCG][4];
-#pragma unroll
-    for (int c = 0; c < EA_MAXCG; ++c)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) oacc[c][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
 
-    for (int k0 = 0; k0 < T; k0 += EA_TK) {
-        // ---- scores of 16 queries x 64 keys, partial over this wave's feature slice
-        f32x4 acc[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int it = 0; it < EA_IT; ++it) {
-            const int f4 = it * 16 + wave * 4 + g4;
-            const bool ok = f4 < EA_F4;
-            const float av[4] = {qf[it].x, qf[it].y, qf[it].z, qf[it].w};
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const float* krow = kb + (long)min(k0 + nt * 16 + l15, T - 1) * EDQK;
-                float4 b4 = *reinterpret_cast<const float4*>(krow + (ok ? f4 * 4 : 0));
-                if (!ok) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[nt], 0, 0, 0);
-            }
-        }
-        __syncthreads();                              // previous tile's pm / frow consumed
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sp[wave][g4 * 4 + r][nt * 16 + l15] = acc[nt][r];
-        __syncthreads();
+// C[M x N] = A[M x K] B[N x K]^T per batch, operands as fp16 hi/lo images (lo image at +imgA / +imgB halves), K a
+// multiple of 32.  128 x 128 tile per workgroup, 4 waves as 2 x 2 (each 64 x 64 = 4 x 4 MFMA tiles, two fp32
+// accumulator sets), one 32-wide k-step per stage: global -> registers -> double-buffered LDS (one barrier per
+// stage), A/B fragments by conflict-free ds_read_b128.  Workgroups of one batch stay on one XCD (its Q/K or P/V^T
+// panel is then read from HBM once per L2 instead of once per XCD).
+constexpr int GM_RP = 130;                        // rows per 16-byte k-block plane (+2: staging writes conflict-free)
+constexpr int GM_IMG = 4 * GM_RP * 8;             // halves per (operand, hi|lo) stage image
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__ A, const _Float16* __restrict__ Bm,
+                                                    float* __restrict__ Cm, int M, int N, int K, int lda, int ldb,
+                                                    long strideA, long strideB, long imgA, long imgB, int ldc,
+                                                    long strideC, float scale, int nbatch, int tiles_m, int tiles_n,
+                                                    int Bn, int T) {
+    __shared__ __attribute__((aligned(16))) _Float16 sm[2][4][GM_IMG];      // [stage][A hi, A lo, B hi, B lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware decode: consecutive workgroup ids go round-robin over the 8 XCDs; keep a batch on one XCD
+    const int ntile = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int batch = (j / ntile) * 8 + xcd, tile = j % ntile;
+    if (batch >= nbatch) return;
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+    const _Float16* Ab = A + (long)batch * strideA;
+    const _Float16* Bb = Bm + (long)batch * strideB;
 
-        // ---- online softmax: 16 threads per query, 4 keys each
-        {
-            const int i = tid >> 4, sub = tid & 15;
-            float sv[4], mx = -3.0e38f;
+    // staging: 128 rows x 4 k-blocks of 16 bytes per image = 512 items, 2 per thread
+    const int sr = tid >> 2, sb = tid & 3;
+    const long a_off0 = (long)min(m0 + sr, M - 1) * lda + sb * 8, a_off1 = (long)min(m0 + sr + 64, M - 1) * lda + sb * 8;
+    const long b_off0 = (long)min(n0 + sr, N - 1) * ldb + sb * 8, b_off1 = (long)min(n0 + sr + 64, N - 1) * ldb + sb * 8;
+    const int s_idx0 = (sb * GM_RP + sr) * 8, s_idx1 = (sb * GM_RP + sr + 64) * 8;
+    f16x8 st[8];
+    auto fetch = [&](int k0) {
+        st[0] = *reinterpret_cast<const f16x8*>(Ab + a_off0 + k0);        st[1] = *reinterpret_cast<const f16x8*>(Ab + a_off1 + k0);
+        st[2] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off0 + k0); st[3] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off1 + k0);
+        st[4] = *reinterpret_cast<const f16x8*>(Bb + b_off0 + k0);        st[5] = *reinterpret_cast<const f16x8*>(Bb + b_off1 + k0);
+        st[6] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off0 + k0); st[7] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off1 + k0);
+    };
+    f32x4 am[4][4], ac[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int n = sub + 16 * u;
-                float sc = -3.0e38f;
-                if (k0 + n < T) sc = (sp[0][i][n] + sp[1][i][n] + sp[2][i][n] + sp[3][i][n]) * scale;
-                sv[u] = sc;
-                mx = fmaxf(mx, sc);
-            }
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            const float mold = mrow[i], mnew = fmaxf(mold, mx);
-            float sum = 0.f;
+        for (int jn = 0; jn < 4; ++jn) { am[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    fetch(0);
+    const int nk = K / 32;
+#pragma unroll 1
+    for (int ks = 0; ks < nk; ++ks) {
+        _Float16* buf = &sm[ks & 1][0][0];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int n = sub + 16 * u;
-                const float pv = (k0 + n < T) ? __expf(sv[u] - mnew) : 0.f;
-                pm[i][n] = pv;
-                sum += pv;
-            }
-            sum = group16_sum(sum);
-            const float fac = __expf(mold - mnew);
-            __syncthreads();                          // every thread has read mrow/lrow of the previous tile
-            if (sub == 0) { mrow[i] = mnew; lrow[i] = lrow[i] * fac + sum; frow[i] = fac; }
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx0]) = st[2 * i];
+            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx1]) = st[2 * i + 1];
         }
         __syncthreads();
-
-        // ---- O = O * fac + P V
-        float fr4[4];
+        if (ks + 1 < nk) fetch((ks + 1) * 32);
+        f16x8 bh[4], bl[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fr4[r] = frow[g4 * 4 + r];
-        float pa[EA_TK / 4];
+        for (int jn = 0; jn < 4; ++jn) {
+            const int idx = (g4 * GM_RP + wn * 64 + jn * 16 + l15) * 8;
+            bh[jn] = *reinterpret_cast<const f16x8*>(&buf[2 * GM_IMG + idx]);
+            bl[jn] = *reinterpret_cast<const f16x8*>(&buf[3 * GM_IMG + idx]);
+        }
 #pragma unroll
-        for (int ks = 0; ks < EA_TK / 4; ++ks) pa[ks] = pm[l15][ks * 4 + g4];
+        for (int i = 0; i < 4; ++i) {
+            const int idx = (g4 * GM_RP + wm * 64 + i * 16 + l15) * 8;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&buf[idx]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
 #pragma unroll
-        for (int c = 0; c < EA_MAXCG; ++c) {
-            const int cg = wave + 4 * c;
-            if (cg < EA_CG) {                         // wave-uniform
-                const int col = cg * 64 + l15 * 4;
-                const int lcol = col < EDV ? col : 0;
+            for (int jn = 0; jn < 4; ++jn) {
+                am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
+                ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], ac[i][jn], 0, 0, 0);
+                ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], ac[i][jn], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: lane holds rows g4*4 + r, column l15 of each 16 x 16 tile -> 64-byte row segments
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) oacc[c][u][r] *= fr4[r];
+        for (int jn = 0; jn < 4; ++jn) {
+            const int col = n0 + wn * 64 + jn * 16 + l15;
 #pragma unroll
-                for (int ks = 0; ks < EA_TK / 4; ++ks) {
-                    const int row = min(k0 + ks * 4 + g4, T - 1);
-                    const float4 v4 = *reinterpret_cast<const float4*>(vb + (long)row * EDV + lcol);
-                    oacc[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.x, oacc[c][0], 0, 0, 0);
-                    oacc[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.y, oacc[c][1], 0, 0, 0);
-                    oacc[c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.z, oacc[c][2], 0, 0, 0);
-                    oacc[c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.w, oacc[c][3], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + g4 * 4 + r;
+                if (row < M && col < N) {
+                    const float val = (am[i][jn][r] + ac[i][jn][r] * (1.0f / ESPLIT)) * scale;
+                    if (EPI == 0) {
+                        Cm[(long)batch * strideC + (long)row * ldc + col] = val;
+                    } else {                     // batch = h*Bn + b, row = frame, col = f*16 + v
+                        const int hd = batch / Bn, b = batch % Bn;
+                        Cm[(((long)b * T + row) * EF + (col >> 4)) * C + hd * VD + (col & 15)] = val;
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    // ---- normalise and store with the head merge fused: V column = f*16 + vv
-    const int hd = bh / B, b = bh % B;
-    float inv[4];
+}
+
+// row softmax of the (already scaled) scores: one wave per row; P as fp16 hi/lo, keys zero-padded to Tp
+__global__ void __launch_bounds__(256) k_emb_softmax(const float* __restrict__ sc, _Float16* __restrict__ p, long rows, int T,
+                                                     int Tp, long img) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = sc + row * Tp;
+    float mx = -3.0e38f;
+    for (int i = lane; i < T; i += 64) mx = fmaxf(mx, sr[i]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) inv[r] = 1.0f / lrow[g4 * 4 + r];
-#pragma unroll
-    for (int c = 0; c < EA_MAXCG; ++c) {
-        const int cg = wave + 4 * c;
-        const int col = cg * 64 + l15 * 4;
-        if (cg < EA_CG && col < EDV) {
-            const int f = col >> 4, vv = col & 15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = t0 + g4 * 4 + r;
-                if (t < T)
-                    *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * EF + f) * C + hd * VD + vv]) =
-                        make_float4(oacc[c][0][r] * inv[r], oacc[c][1][r] * inv[r], oacc[c][2][r] * inv[r], oacc[c][3][r] * inv[r]);
-            }
-        }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int i = lane; i < T; i += 64) sum += __expf(sr[i] - mx);
+    const float inv = 1.0f / wave_sum(sum);
+    _Float16* ph = p + row * Tp;
+    _Float16* pl = ph + img;
+    for (int i = lane; i < Tp; i += 64) {
+        const float x = i < T ? __expf(sr[i] - mx) * inv : 0.f;
+        const _Float16 h = (_Float16)x;
+        ph[i] = h;
+        pl[i] = (_Float16)((x - (float)h) * ESPLIT);
     }
 }
 
@@ -967,29 +1057,33 @@ extern "C" int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_
 // One axis path of a GridNetBlock: inter = 0 along frequency (sequences = frames), 1 along time (sequences = bins).
 //   x, out [B][T][65][64] (must not alias); wih_pk fp16 hi/lo image [32 ntiles][8 ksteps][64][16] of the folded,
 //   column-permuted input weights of both directions; bih [512]; whh_pk [2][4][4][2][64][16]; wct_pk [4][16][64][16]
-//   (ConvTranspose1d taps as [64 out] x [4*128]); bct [64]; gx scratch [nseq*P][512]; hbuf scratch [nseq*P][128]
+//   (ConvTranspose1d taps as [64 out] x [4*128]); bct [64]; xsplit scratch 2*B*T*65*64 fp16 (hi | lo images of the
+//   channel-normalised input); gx scratch [nseq*P][512]; hbuf scratch [nseq*P][128]
 extern "C" int lh_emb_axis(const float* x, const void* wih_pk, const float* bih, const void* whh_pk, const void* wct_pk,
-                           const float* bct, float* gx, float* hbuf, float* out, int B, int T, int inter,
+                           const float* bct, void* xsplit, float* gx, float* hbuf, float* out, int B, int T, int inter,
                            lh_stream_t stream) {
     using namespace lh;
-    if (!x || !wih_pk || !bih || !whh_pk || !wct_pk || !bct || !gx || !hbuf || !out || B <= 0 || T < EKS || x == out)
+    if (!x || !wih_pk || !bih || !whh_pk || !wct_pk || !bct || !xsplit || !gx || !hbuf || !out || B <= 0 || T < EKS ||
+        x == out)
         return LH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nseq = inter ? B * EF : B * T;
     const int P = (inter ? T : EF) - (EKS - 1);
-    const long grows = (long)nseq * P;
-    const int gtiles = (int)((grows + 63) / 64);
+    const int gtiles = nseq * ((P + 63) / 64);
     const long rows = (long)B * T * EF;
     const int ctiles = (int)((rows + 31) / 32);
+    const int gxgrid = gtiles < 128 ? gtiles : 128;                 // x 4 column chunks = 2 workgroups per CU
+    const long lnb = (rows + 15) / 16;
+    hipLaunchKernelGGL(k_emb_lnsplit, dim3((unsigned)(lnb < 4096 ? lnb : 4096)), dim3(256), 0, st, x, (_Float16*)xsplit, rows);
     if (inter) {
-        hipLaunchKernelGGL((k_emb_gx<true>), dim3(gtiles < 64 ? gtiles : 64, 4), dim3(256), 0, st, x, (const _Float16*)wih_pk,
-                           bih, gx, nseq, P, T);
+        hipLaunchKernelGGL((k_emb_gx<true>), dim3(gxgrid, 4), dim3(256), 0, st, (const _Float16*)xsplit,
+                           (const _Float16*)wih_pk, bih, gx, nseq, P, T, rows);
         hipLaunchKernelGGL(k_emb_lstm, dim3((nseq + 15) / 16, 2), dim3(256), 0, st, gx, (const _Float16*)whh_pk, hbuf, nseq, P);
         hipLaunchKernelGGL((k_emb_convt_res<true>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, hbuf,
                            (const _Float16*)wct_pk, bct, x, out, rows, P, T);
     } else {
-        hipLaunchKernelGGL((k_emb_gx<false>), dim3(gtiles < 64 ? gtiles : 64, 4), dim3(256), 0, st, x, (const _Float16*)wih_pk,
-                           bih, gx, nseq, P, T);
+        hipLaunchKernelGGL((k_emb_gx<false>), dim3(gxgrid, 4), dim3(256), 0, st, (const _Float16*)xsplit,
+                           (const _Float16*)wih_pk, bih, gx, nseq, P, T, rows);
         hipLaunchKernelGGL(k_emb_lstm, dim3((nseq + 15) / 16, 2), dim3(256), 0, st, gx, (const _Float16*)whh_pk, hbuf, nseq, P);
         hipLaunchKernelGGL((k_emb_convt_res<false>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, hbuf,
                            (const _Float16*)wct_pk, bct, x, out, rows, P, T);
@@ -997,26 +1091,40 @@ extern "C" int lh_emb_axis(const float* x, const void* wih_pk, const float* bih,
     return check_launch();
 }
 
-// Attention branch of one GridNetBlock: Q/K/V frame kernel, full attention, projection + LayerNorm + residual.
-//   y2, out [B][T][65][64]; merged scratch [B][T][65][64]; q, k scratch [4B][T][520]; v scratch [4B][T][1040];
+// Attention branch of one GridNetBlock: Q/K/V frame kernel, V transpose, score GEMM, softmax, P.V GEMM with fused
+// head merge, projection + LayerNorm + residual.  Tp = T rounded up to 64.
+//   y2, out [B][T][65][64]; merged scratch [B][T][65][64]
+//   q, k  scratch fp16 [2][4B][T][544]   (hi | lo images);  v scratch fp32 [4B][T][1040]
+//   vt    scratch fp16 [2][4B][1040][Tp]; sc scratch fp32 [4B][T][Tp]; p scratch fp16 [2][4B][T][Tp]
 //   wqkv_pk fp16 hi/lo image [8][2][64][16] of the stacked 1x1-conv weights [128 x 64]; bqkv, slopes [128];
 //   lnq/lnk [4][520], lnv [4][1040] affine in flat (f*d + c) order; wproj_pk [4][2][64][16]; bproj [64]; slope_p [1];
 //   lnp_w/b [4160] in flat (f*64 + c) order
 extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const float* bqkv, const float* slopes,
                                  const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
                                  const float* lnv_w, const float* lnv_b, const void* wproj_pk, const float* bproj,
-                                 const float* slope_p, const float* lnp_w, const float* lnp_b, float* q, float* k, float* v,
-                                 float* merged, float* out, int B, int T, lh_stream_t stream) {
+                                 const float* slope_p, const float* lnp_w, const float* lnp_b, void* q, void* k, float* v,
+                                 void* vt, float* sc, void* p, float* merged, float* out, int B, int T,
+                                 lh_stream_t stream) {
     using namespace lh;
     if (!y2 || !wqkv_pk || !bqkv || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !wproj_pk ||
-        !bproj || !slope_p || !lnp_w || !lnp_b || !q || !k || !v || !merged || !out || B <= 0 || T <= 0)
+        !bproj || !slope_p || !lnp_w || !lnp_b || !q || !k || !v || !vt || !sc || !p || !merged || !out || B <= 0 || T <= 0)
         return LH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int nframes = B * T;
+    const int nframes = B * T, nb = NH * B, Tp = (T + 63) / 64 * 64;
     hipLaunchKernelGGL(k_emb_qkv, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, st, y2, (const _Float16*)wqkv_pk, bqkv,
-                       slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, q, k, v, B, T);
-    const int ntq = (T + EA_TQ - 1) / EA_TQ;
-    hipLaunchKernelGGL(k_emb_attn, dim3(NH * B * ntq), dim3(256), 0, st, q, k, v, merged, B, T, ntq);
+                       slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, (_Float16*)q, (_Float16*)k, v, B, T);
+    const long img_qk = (long)nb * T * EQP, img_vt = (long)nb * EDV * Tp, img_p = (long)nb * T * Tp;
+    hipLaunchKernelGGL(k_emb_vt, dim3(Tp / 64, (EDV + 63) / 64, nb), dim3(256), 0, st, v, (_Float16*)vt, T, Tp, img_vt);
+    const int nb8 = (nb + 7) / 8 * 8;
+    const int tm = (T + 127) / 128;
+    hipLaunchKernelGGL((k_gemm_nt<0>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc, T, T,
+                       EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
+                       1.0f / sqrtf((float)EDQK), nb, tm, tm, B, T);
+    const long rows = (long)nb * T;
+    hipLaunchKernelGGL(k_emb_softmax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sc, (_Float16*)p, rows, T, Tp, img_p);
+    const int tn = (EDV + 127) / 128;
+    hipLaunchKernelGGL((k_gemm_nt<1>), dim3(nb8 * tm * tn), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt, merged, T,
+                       EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn, B, T);
     hipLaunchKernelGGL(k_emb_proj, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, st, merged, (const _Float16*)wproj_pk,
                        bproj, slope_p, lnp_w, lnp_b, y2, out, nframes);
     return check_launch();

@@ -126,7 +126,7 @@ class EmbedTFGridNet(nn.Module):
                         e0.record()
                         lib_.call(name, *args)
                         e1.record()
-                        prof.append((name + ("" if name != "lh_emb_axis" else (".inter" if args[11] else ".intra")), e0, e1))
+                        prof.append((name + ("" if name != "lh_emb_axis" else (".inter" if args[12] else ".intra")), e0, e1))
             za, zb, zc = e(B, T, F_, C_), e(B, T, F_, C_), e(B, T, F_, C_)
             inv_std = e(B)
             tiles = B * ((T + 13) // 14)
@@ -138,19 +138,23 @@ class EmbedTFGridNet(nn.Module):
             P_i, P_e = F_ - 3, T - 3
             gx = e(max(B * T * P_i, B * F_ * P_e) * 512)
             hbuf = e(max(B * T * P_i, B * F_ * P_e) * 128)
-            qb, kb = e(self.n_head * B * T * F_ * self.E), e(self.n_head * B * T * F_ * self.E)
+            xsp = e(B, T, F_, C_)              # fp16 hi | lo images of the normalised axis input (same bytes as fp32)
+            nb, Tp = self.n_head * B, (T + 63) // 64 * 64
+            h16 = lambda n: torch.empty(n, device=dev, dtype=torch.float16)
+            qb, kb = h16(2 * nb * T * 544), h16(2 * nb * T * 544)       # fp16 hi | lo images, rows padded 520 -> 544
             vb = e(B * T * F_ * C_)
+            vtb, scb, pb = h16(2 * nb * 1040 * Tp), e(nb * T * Tp), h16(2 * nb * T * Tp)
             for i in range(self.n_layers):
                 bp = pk["blocks"][i]
                 lib.call("lh_emb_axis", P(za), P(bp["intra_wih"]), P(bp["intra_bih"]), P(bp["intra_whh"]), P(bp["intra_wct"]),
-                         P(bp["intra_bct"]), P(gx), P(hbuf), P(zb), B, T, 0, st)
+                         P(bp["intra_bct"]), P(xsp), P(gx), P(hbuf), P(zb), B, T, 0, st)
                 lib.call("lh_emb_axis", P(zb), P(bp["inter_wih"]), P(bp["inter_bih"]), P(bp["inter_whh"]), P(bp["inter_wct"]),
-                         P(bp["inter_bct"]), P(gx), P(hbuf), P(zc), B, T, 1, st)
+                         P(bp["inter_bct"]), P(xsp), P(gx), P(hbuf), P(zc), B, T, 1, st)
                 if taps is not None:
                     taps[f"blocks.{i}.x1"], taps[f"blocks.{i}.x2"] = zb.clone(), zc.clone()
                 lib.call("lh_emb_attn_block", P(zc), P(bp["wqkv"]), P(bp["bqkv"]), P(bp["slopes"]), P(bp["lnq_w"]),
                          P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(bp["wproj"]),
-                         P(bp["bproj"]), P(bp["slope_p"]), P(bp["lnp_w"]), P(bp["lnp_b"]), P(qb), P(kb), P(vb), P(zb), P(za),
+                         P(bp["bproj"]), P(bp["slope_p"]), P(bp["lnp_w"]), P(bp["lnp_b"]), P(qb), P(kb), P(vb), P(vtb), P(scb), P(pb), P(zb), P(za),
                          B, T, st)
                 if taps is not None:
                     taps[f"blocks.{i}.O"], taps[f"blocks.{i}.out"] = zb.clone(), za.clone()
