@@ -1,0 +1,69 @@
+"""profiles/pmc_traffic.json from the two PMC passes (FETCH_SIZE, WRITE_SIZE) summarised by scripts/rocpd_summary.py.
+
+    python scripts/make_pmc_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <batch> <out.json>
+
+Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950
+FETCH_SIZE tallies 128-byte requests as 64 bytes, so it is doubled; WRITE_SIZE is used as is.  Values are averages per
+kernel launch (dispatch).  The same kernel function serves several C-ABI calls; launches are told apart by grid size.
+"""
+import csv
+import json
+import sys
+
+T, F = 625, 97
+
+
+def load(path):
+    out = {}
+    for row in csv.reader(open(path)):
+        if len(row) == 5 and row[0] != "kernel" and not row[0].startswith("#"):
+            out[(row[0], int(row[1]))] = (int(row[3]), float(row[4]))
+    return out
+
+
+def main(fetch_csv, write_csv, batch, out_json):
+    B = int(batch)
+    fe, wr = load(fetch_csv), load(write_csv)
+    A = 15.52e6 * B
+    qk = 5.82e6 * B
+    wg = lambda nseq: ((nseq + 15) // 16) * 256          # LSTM launches: 16 sequences per 256-thread workgroup
+    # C-ABI call -> (kernel-name substring, grid size or None, algorithmic bytes per kernel launch)
+    table = {
+        "lh_intra_block": ("k_ln_lstm_lin", wg(B * T), 2.5 * A),
+        "lh_inter_block": ("k_ln_lstm_lin", wg(B * F), 2.0 * A),
+        "lh_qkv_proj_ln": ("k_qkv_proj_ln", None, 2 * A + 2 * qk),
+        "lh_local_attn": ("k_local_attn", None, 2 * qk + 2 * A),
+        "lh_proj_ln_res": ("k_proj_ln_res", None, 3 * A),
+        "lh_stft_conv_in": ("k_stft_conv_in", None, 16.16e6 * B),
+        "lh_deconv_istft": ("k_deconv_istft", None, 16.16e6 * B),
+    }
+    kernels = {}
+    for call, (pat, grid, alg) in table.items():
+        f = [(k, v) for k, v in fe.items() if pat in k[0] and (grid is None or k[1] == grid)]
+        w = [(k, v) for k, v in wr.items() if pat in k[0] and (grid is None or k[1] == grid)]
+        if not f or not w:
+            continue
+        fn = sum(v[0] for _, v in f); wn = sum(v[0] for _, v in w)
+        fetch_kib = sum(v[0] * v[1] for _, v in f) / fn
+        write_kib = sum(v[0] * v[1] for _, v in w) / wn
+        kernels[call] = {
+            "kernel": f[0][0][0], "grid_size": f[0][0][1], "dispatches": fn,
+            "fetch_bytes_per_launch": 2 * 1024 * fetch_kib, "write_bytes_per_launch": 1024 * write_kib,
+            "hbm_bytes_per_launch": 2 * 1024 * fetch_kib + 1024 * write_kib,
+            "algorithmic_bytes_per_launch": alg,
+        }
+        kernels[call]["ratio_to_algorithmic"] = kernels[call]["hbm_bytes_per_launch"] / alg
+    json.dump({
+        "source": f"{fetch_csv} + {write_csv} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                  "summarised by scripts/rocpd_summary.py --pmc)",
+        "batch_per_gpu": B,
+        "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM "
+                       "section); WRITE_SIZE uncorrected",
+        "kernels": kernels}, open(out_json, "w"), indent=1)
+    for k, v in kernels.items():
+        print(f"{k:18s} {v['hbm_bytes_per_launch'] / 1e9:8.3f} GB measured  {v['algorithmic_bytes_per_launch'] / 1e9:8.3f} GB algorithmic"
+              f"  x{v['ratio_to_algorithmic']:.2f}")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])

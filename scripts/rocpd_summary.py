@@ -24,6 +24,19 @@ def main(db, out, pmc=False):
             for name, calls, tot, avg, pct in rows:
                 w.writerow([short(name), calls, f"{tot / 1e3:.1f}" if tot > 1e6 else f"{tot:.1f}", f"{avg:.1f}", f"{pct:.2f}"])
             print("wrote", out, len(rows), "kernels")
+            # the same kernel serves several stages (e.g. k_ln_lstm_lin: intra and inter): split by launch grid
+            try:
+                kc = [r[1] for r in c.execute("pragma table_info(kernels)")]
+                gcol = "grid_size" if "grid_size" in kc else "grid_size_x"
+                rows = c.execute(f"select name, {gcol}, count(*), avg(end - start), sum(end - start) from kernels "
+                                 f"group by name, {gcol} order by 5 desc").fetchall()
+                w.writerow([])
+                w.writerow(["kernel", "grid_size", "calls", "avg_us", "total_us"])
+                for name, g, n, avg, tot in rows:
+                    if "lh::" in name or "_ZN2lh" in name:
+                        w.writerow([short(name), g, n, f"{avg / 1e3:.1f}", f"{tot / 1e3:.1f}"])
+            except Exception as e:  # schema differs between rocprofv3 versions: the view above is enough
+                w.writerow(["# per-grid split unavailable: %s" % e])
             return
         cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
         w.writerow(["# counters_collection columns: " + " ".join(cols)])
@@ -34,15 +47,16 @@ def main(db, out, pmc=False):
             print("unknown schema", cols)
             return
         did = "dispatch_id" if "dispatch_id" in cols else None
-        q = (f"select {kcol}, {ccol}, count(*), sum({vcol}) from counters_collection group by {kcol}, {ccol}")
+        g = "grid_size" if "grid_size" in cols else "0"
+        q = (f"select {kcol}, {g}, {ccol}, count(*), sum({vcol}) from counters_collection group by {kcol}, {g}, {ccol}")
         if did:  # a counter may have several rows per dispatch (per XCC/instance): sum within a dispatch first
-            q = (f"select k, cn, count(*), avg(v) from (select {kcol} as k, {ccol} as cn, {did} as d, sum({vcol}) as v "
-                 f"from counters_collection group by {kcol}, {ccol}, {did}) group by k, cn")
-        w.writerow(["kernel", "counter", "dispatches", "avg_per_dispatch"])
+            q = (f"select k, g, cn, count(*), avg(v) from (select {kcol} as k, {g} as g, {ccol} as cn, {did} as d, "
+                 f"sum({vcol}) as v from counters_collection group by {kcol}, {g}, {ccol}, {did}) group by k, g, cn")
+        w.writerow(["kernel", "grid_size", "counter", "dispatches", "avg_per_dispatch"])
         n = 0
-        for k, cn, cnt, v in c.execute(q):
+        for k, gs, cn, cnt, v in c.execute(q):
             if "lh::" in k or "_ZN2lh" in k:
-                w.writerow([short(k), cn, cnt, f"{v:.6g}"])
+                w.writerow([short(k), gs, cn, cnt, f"{v:.6g}"])
                 n += 1
         print("wrote", out, n, "rows")
 
