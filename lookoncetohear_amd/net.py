@@ -122,6 +122,9 @@ class Net(nn.Module):
                  use_attn=False, lookahead=True, local_atten_len=100,
                  chunk_causal=False, num_src=2):
         super().__init__()
+        self.ctor_params = dict(stft_chunk_size=stft_chunk_size, stft_pad_size=stft_pad_size, embed_dim=embed_dim,
+                                num_ch=num_ch, D=D, B=B, I=I, J=J, L=L, H=H, use_attn=use_attn, lookahead=lookahead,
+                                local_atten_len=local_atten_len, chunk_causal=chunk_causal, num_src=num_src)
         self.stft_chunk_size = stft_chunk_size
         self.stft_pad_size = stft_pad_size
         self.num_ch = num_ch

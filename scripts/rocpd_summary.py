@@ -24,19 +24,41 @@ def main(db, out, pmc=False):
             for name, calls, tot, avg, pct in rows:
                 w.writerow([short(name), calls, f"{tot / 1e3:.1f}" if tot > 1e6 else f"{tot:.1f}", f"{avg:.1f}", f"{pct:.2f}"])
             print("wrote", out, len(rows), "kernels")
-            # the same kernel serves several stages (e.g. k_ln_lstm_lin: intra and inter): split by launch grid
-            try:
-                kc = [r[1] for r in c.execute("pragma table_info(kernels)")]
-                gcol = "grid_size" if "grid_size" in kc else "grid_size_x"
-                rows = c.execute(f"select name, {gcol}, count(*), avg(end - start), sum(end - start) from kernels "
-                                 f"group by name, {gcol} order by 5 desc").fetchall()
-                w.writerow([])
+            # the same kernel serves several stages (e.g. k_ln_lstm_lin: intra and inter): split by launch grid.
+            # rocpd schemas differ between versions: discover a table/view with a kernel name, a grid size and times.
+            w.writerow([])
+            done = False
+            objs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+            for t in sorted(objs, key=lambda n: (not n.startswith("kernels"), n)):
+                try:
+                    tc = [r[1] for r in c.execute(f"pragma table_info('{t}')")]
+                except Exception:
+                    continue
+                ncol = next((x for x in ("name", "kernel_name", "kernel") if x in tc), None)
+                if "grid_size" in tc:
+                    gexpr = "grid_size"
+                elif all(x in tc for x in ("grid_size_x", "grid_size_y", "grid_size_z")):
+                    gexpr = "grid_size_x * grid_size_y * grid_size_z"
+                elif all(x in tc for x in ("grid_x", "grid_y", "grid_z")):
+                    gexpr = "grid_x * grid_y * grid_z"
+                else:
+                    gexpr = None
+                if not (ncol and gexpr and "start" in tc and "end" in tc):
+                    continue
+                try:
+                    rows = c.execute(f"select {ncol}, {gexpr}, count(*), avg(end - start), sum(end - start) from '{t}' "
+                                     f"group by 1, 2 order by 5 desc").fetchall()
+                except Exception:
+                    continue
+                w.writerow([f"# per (kernel, grid size) from {t}"])
                 w.writerow(["kernel", "grid_size", "calls", "avg_us", "total_us"])
                 for name, g, n, avg, tot in rows:
-                    if "lh::" in name or "_ZN2lh" in name:
+                    if isinstance(name, str) and ("lh::" in name or "_ZN2lh" in name):
                         w.writerow([short(name), g, n, f"{avg / 1e3:.1f}", f"{tot / 1e3:.1f}"])
-            except Exception as e:  # schema differs between rocprofv3 versions: the view above is enough
-                w.writerow(["# per-grid split unavailable: %s" % e])
+                done = True
+                break
+            if not done:
+                w.writerow(["# per-grid split unavailable; tables/views: " + " ".join(objs)])
             return
         cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
         w.writerow(["# counters_collection columns: " + " ".join(cols)])
