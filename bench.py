@@ -214,6 +214,71 @@ def bench_embed(args, dev, rank, world, dist):
         "embedding_norm_mean": float(emb.norm(dim=1).mean())}))
 
 
+def bench_render(args, dev, rank, world, dist):
+    """binaural rendering of `batch` utterances x (3 sources + noise) x 5 s with `--rir-len`-tap
+    2-ear impulse responses (256 = HRIR-length at 16 kHz, 4096 = BRIR-length).  A step = render + mix of the batch."""
+    import numpy as np
+    from lookoncetohear_amd.render import BinauralRenderer
+    from oracle import render_oracle as R
+    B = 64 if args.batch == 32 else args.batch
+    N, Lh, S1 = 80000, args.rir_len, 4
+    sc = [R.synthetic_scene(rank * 8 + i, N, 3, Lh, reverb=Lh > 1024) for i in range(min(B, 8))]
+    rep = (B + len(sc) - 1) // len(sc)
+    srcs = torch.from_numpy(np.stack([s[0] for s in sc])).repeat(rep, 1, 1)[:B].contiguous().to(dev)
+    rirs = torch.from_numpy(np.stack([s[1] for s in sc])).repeat(rep, 1, 1, 1)[:B].contiguous().to(dev)
+    gains = torch.ones(B, S1, device=dev)
+    gains[:, 3] = torch.tensor([s[2] for s in sc]).repeat(rep)[:B].to(dev)
+    tgt = torch.tensor([s[3] for s in sc]).repeat(rep)[:B].to(dev)
+    rr = BinauralRenderer()
+    for _ in range(args.warmup):
+        rr.render(srcs, rirs, gains, tgt)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        out = rr.render(srcs, rirs, gains, tgt)
+    e1.record()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if rank != 0:
+        return
+    call_ms = e0.elapsed_time(e1) / args.steps
+    flops = 2.0 * N * Lh * S1 * 2 * B                       # FIR MACs x 2 (upper bound: ignores the start-up triangle)
+    bytes_ = (S1 * N + S1 * 2 * N * 3 + 2 * 2 * N) * 4.0 * B  # src in, events out + 2 reads by the mix, mixture + target out
+    valu = flops / (call_ms * 1e-3) / 1e12
+    hbm = bytes_ / (call_ms * 1e-3) / 1e9
+    compute_bound = valu / PEAK_FP32_MFMA_TFLOPS > hbm / PEAK_HBM_GBS
+    cpu = None
+    if not args.no_cpu_baseline:
+        t1 = time.perf_counter()
+        R.render(*sc[0])
+        dt = time.perf_counter() - t1
+        cpu = {"value": 1.0 / dt, "unit": "utterances/s", "cores": 1, "kind": "port",
+               "sample": "oracle/render_oracle.py = the reference's scipy.signal.convolve calls, 1 utterance (4 rows x 2 ears)"}
+    print(json.dumps({
+        "metric": "binaural rendering utterances_per_sec (3 sources + noise, 5 s 16 kHz, 2 ears)",
+        "value": world * B * args.steps / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"SURVEY 8f-3: {B} utterances x 4 rows x 80000 samples, {Lh}-tap 2-ear responses", "batch_per_gpu": B},
+        "roofline": ({"kernel": "lh_render_binaural (k_fir_causal dominant)", "bound": "mfma", "achieved": valu,
+                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": valu / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                      "note": "fp32 vector FMA (v_pk_fma_f32): same 157 TFLOP/s peak as the fp32 MFMA; not a matrix-core kernel"}
+                     if compute_bound else
+                     {"kernel": "lh_render_binaural", "bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": hbm / PEAK_HBM_GBS, "traffic": None}),
+        "avg_call_ms": call_ms, "cpu_baseline": cpu, "norm_factor_mean": float(out[2].mean())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,10 +286,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE configs[2] = 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="offline", choices=["offline", "stream", "embed"],
+    ap.add_argument("--mode", default="offline", choices=["offline", "stream", "embed", "render"],
                     help="offline = BASELINE configs[2] (default, the headline line); stream = configs[1]: 8 ms chunks, "
                          "carried state, HIP-graph replay per chunk (a step = one chunk)")
     ap.add_argument("--gemm", default=None, choices=["f32", "f16x3"], help="override Net.gemm_mode (A/B runs)")
+    ap.add_argument("--rir-len", type=int, default=256, help="--mode render: taps per impulse response")
     ap.add_argument("--tune", default="", help="comma list key=value for lh_set_tuning (A/B runs), e.g. 0=2,1=1")
     args = ap.parse_args()
 
@@ -244,6 +310,9 @@ def main():
     if args.mode == "embed":
         _cabi.load()
         return bench_embed(args, dev, rank, world, dist)
+    if args.mode == "render":
+        _cabi.load()
+        return bench_render(args, dev, rank, world, dist)
     from lookoncetohear_amd.net import Net
     from lookoncetohear_amd.metrics import metric_sums_device
     from oracle import tfgridnet_oracle as O

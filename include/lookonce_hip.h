@@ -219,6 +219,20 @@ int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const float* bqkv, c
 int lh_emb_head(const float* z, const void* w_pk, const float* bias, const float* ln_w, const float* ln_b,
                 float* part, float* emb, int B, int T, lh_stream_t stream);
 
+/* Binaural rendering, the data-pipeline step before the separator (reference src/datasets/multi_ch_simulator.py:40-61
+ * `_convolve` = `scipy.signal.convolve(src, rir[ear])[:len(src)]` per source and ear;
+ * src/datasets/MixLibriSpeechNoisyEnrollNorm.py:176-202 noise scale, peak normalisation, mixture, target).
+ *   src      [B][S1][N]       mono rows: the sources first, the noise bed LAST
+ *   rir      [B][S1][2][Lh]   impulse response per row and ear (shorter ones zero-padded to Lh)
+ *   gain     [B][S1]          applied after the convolution: 1 for sources, `noise_scale` for the noise row
+ *   tgt_idx  [B] int32        row returned as `target`
+ *   events   [B][S1][2][N]    out: rendered rows before peak normalisation
+ *   peak     [B] uint32       out: bit pattern of the fp32 peak of |mixture| (the reference's `norm_factor`)
+ *   mixture, target [B][2][N] out: divided by the peak when it exceeds 1 (IEEE division, reference order of sums)
+ */
+int lh_render_binaural(const float* src, const float* rir, const float* gain, const int* tgt_idx, float* events,
+                       unsigned* peak, float* mixture, float* target, int B, int S1, int N, int Lh, lh_stream_t stream);
+
 /* Eval metrics on the device (reference src/ts_hear_test.py:139-146, torchmetrics SI-SNR restated): per utterance
  * output_sisnr, si_snr_i (both averaged over the 2 channels) and cosine(embedding, embedding_gt); fp64 moments.
  *   outputs, target, mixture [B][2][n_samples]; emb, emb_gt [B][emb_dim]

@@ -36,6 +36,7 @@ SIGNATURES = {
     "lh_emb_axis": [_P] * 10 + [_I, _I, _I, _P],
     "lh_emb_attn_block": [_P] * 23 + [_I, _I, _P],
     "lh_emb_head": [_P] * 7 + [_I, _I, _P],
+    "lh_render_binaural": [_P] * 8 + [_I, _I, _I, _I, _P],
     "lh_metric_sums": [_P] * 8 + [_I, _I, _I, _P],
 }
 ERRORS = {1: "LH_ERR_ARG", 2: "LH_ERR_UNSUPPORTED", 3: "LH_ERR_LAUNCH"}
