@@ -145,7 +145,7 @@ int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const fl
  * the head merge fused into the store.  Replaces tfgridnet_causal.py:564-581 without materialising the
  * 50x unfolded K/V (`_causal_unfold_chunk`, :429-454).
  *   q [B*4][T][584]; kx [B*4][T+49][584]; vx [B*4][T+49][1552]
- *   merged [B][T][97][64]   merged[b][t][f][h*16+v] = O[b*4+h][t][f*16+v]
+ *   merged [B][T][4][97][16]   merged[b][t][h][f][v] = O[b*4+h][t][f*16+v]   (head-major frame slabs)
  */
 int lh_local_attn(const float* q, const float* kx, const float* vx, float* merged, int B, int T,
                   lh_stream_t stream);
@@ -153,7 +153,7 @@ int lh_local_attn(const float* q, const float* kx, const float* vx, float* merge
 /* A.3.6  attn_concat_proj: Linear(64->64)+PReLU, joint LayerNorm over (f,c), residual; optional speaker gain.
  * Replaces tfgridnet_causal.py:583-588 and, when gain != NULL, the `batch = batch * embed` applied to the
  * input of block 1 (:250-251):  out = (y2 + LN(PReLU(W m + b))) * gain[b][f][c].
- *   merged, y2, out [B][T][97][64]; w_pk fp16 hi/lo image [4][2][64][16]; bias [64]; slope [1]; ln_w/b [6208]; gain [B][97][64]|NULL
+ *   merged [B][T][4][97][16] (lh_local_attn's output order); y2, out [B][T][97][64]; w_pk fp16 hi/lo image [4][2][64][16]; bias [64]; slope [1]; ln_w/b [6208]; gain [B][97][64]|NULL
  */
 int lh_proj_ln_res(const float* merged, const void* w_pk, const float* bias, const float* slope,
                    const float* ln_w, const float* ln_b, const float* y2, const float* gain, float* out, int B,

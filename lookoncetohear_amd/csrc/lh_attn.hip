@@ -5,7 +5,9 @@
 // one (batch, head): the 65 history-extended K/V rows they can see are read ONCE from the ring-extended
 // buffers, scores are a banded 16 x 80 fp32-MFMA product split over the feature axis across the 4 waves,
 // softmax runs over exactly the 50 in-window slots (zero history rows take part, no mask — reference
-// behaviour), and P.V streams V rows as 256-byte float4 row segments straight into MFMA B operands.
+// behaviour), and P.V streams V rows as 256-byte float4 row segments straight into MFMA B operands.  The output
+// keeps the head-major order [B][T][head][97][16] (full-line stores; interleaving the heads at 64-byte granularity
+// made every cache line a partial write of two workgroups) — the projection kernel reads it in that order.
 // Workgroups of one (batch, head) are placed on one XCD (blockIdx % 8) so neighbouring tiles re-read the
 // shared 49 rows from that XCD's L2 instead of HBM.
 #include "lh_common.h"
@@ -45,22 +47,36 @@ __global__ void __launch_bounds__(256) k_local_attn(const float* __restrict__ q,
         const float* krow[AT_NKT];
 #pragma unroll
         for (int nt = 0; nt < AT_NKT; ++nt) krow[nt] = kb + (long)min(t0 + nt * 16 + l15, TK - 1) * LDQK;
-#pragma unroll 2
-        for (int it = 0; it < (AT_F4 + 15) / 16; ++it) {
+        // two-deep register ring over the feature iterations: the 6 row segments of iteration it+1 are in flight
+        // while the 20 MFMAs of iteration it run (the compiler otherwise waits for every load right before its use)
+        constexpr int NIT = (AT_F4 + 15) / 16;
+        float4 ring[2][AT_NKT + 1];
+        auto fetch = [&](int it, float4 (&dst)[AT_NKT + 1]) {
             const int f4 = it * 16 + wave * 4 + g4;
-            const bool ok = f4 < AT_F4;
-            const int off = ok ? f4 * 4 : 0;
-            float4 a4 = *reinterpret_cast<const float4*>(qrow + off);
-            if (!ok) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            const int off = f4 < AT_F4 ? f4 * 4 : 0;
+            dst[AT_NKT] = *reinterpret_cast<const float4*>(qrow + off);
+#pragma unroll
+            for (int nt = 0; nt < AT_NKT; ++nt) dst[nt] = *reinterpret_cast<const float4*>(krow[nt] + off);
+        };
+        auto mma = [&](int it, const float4 (&src)[AT_NKT + 1]) {
+            const bool ok = it * 16 + wave * 4 + g4 < AT_F4;
+            const float4 a4 = src[AT_NKT];
+            const float av[4] = {ok ? a4.x : 0.f, ok ? a4.y : 0.f, ok ? a4.z : 0.f, ok ? a4.w : 0.f};
 #pragma unroll
             for (int nt = 0; nt < AT_NKT; ++nt) {
-                float4 b4 = *reinterpret_cast<const float4*>(krow[nt] + off);
-                if (!ok) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                const float bv[4] = {src[nt].x, src[nt].y, src[nt].z, src[nt].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[nt], 0, 0, 0);
             }
+        };
+        static_assert(NIT % 2 == 0, "ring parity");
+        fetch(0, ring[0]);
+#pragma unroll 1
+        for (int it = 0; it < NIT; it += 2) {
+            fetch(it + 1, ring[1]);
+            mma(it, ring[0]);
+            fetch(min(it + 2, NIT - 1), ring[0]);
+            mma(it + 1, ring[1]);
         }
 #pragma unroll
         for (int nt = 0; nt < AT_NKT; ++nt)
@@ -114,29 +130,46 @@ __global__ void __launch_bounds__(256) k_local_attn(const float* __restrict__ q,
 #pragma unroll
         for (int ks = 0; ks < AT_KS; ++ks) pa[ks] = pm[l15][ks * 4 + g4];
         const int b = bh / NH, hd = bh % NH;
-        for (int cg = wave; cg < AT_CG; cg += 4) {
+        // V-row ring: slot ks is refilled with the next column group's row segment right after its 4 MFMAs, so
+        // every load has the other 16 k-steps (64 MFMAs) to land
+        int vrow[AT_KS];
+#pragma unroll
+        for (int ks = 0; ks < AT_KS; ++ks) vrow[ks] = min(t0 + ks * 4 + g4, TK - 1);
+        auto vcol = [&](int cg) { const int c = min(cg, AT_CG - 1) * 64 + l15 * 4; return c < DV ? c : 0; };
+        float4 vr[AT_KS];
+        {
+            const int lc = vcol(wave);
+#pragma unroll
+            for (int ks = 0; ks < AT_KS; ++ks) vr[ks] = *reinterpret_cast<const float4*>(vb + (long)vrow[ks] * DV + lc);
+        }
+        // fully unrolled (7 column groups for wave 0, 6 for the others): exact vmcnt waits instead of a drain of the
+        // ring at every loop back-edge
+#pragma unroll
+        for (int ci = 0; ci < (AT_CG + 3) / 4; ++ci) {
+            const int cg = wave + 4 * ci;
+            if (cg >= AT_CG) break;                    // wave-uniform
             const int col = cg * 64 + l15 * 4;
             const bool colok = col < DV;
-            const int lcol = colok ? col : 0;
+            const int ncol = vcol(cg + 4);
             f32x4 acc[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < AT_KS; ++ks) {
-                const int row = min(t0 + ks * 4 + g4, TK - 1);
-                const float4 v4 = *reinterpret_cast<const float4*>(vb + (long)row * DV + lcol);
+                const float4 v4 = vr[ks];
+                vr[ks] = *reinterpret_cast<const float4*>(vb + (long)vrow[ks] * DV + ncol);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.x, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.y, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.z, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.w, acc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // keep the refill next to its slot's MFMAs (the scheduler sinks it)
             }
             if (colok) {
-                const int f = col >> 4, v = col & 15;        // column = f*16 + v
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = t0 + g4 * 4 + r;
-                    if (t < T)
-                        *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * NF + f) * C + hd * VD + v]) =
+                    if (t < T)      // head-major slab [b][t][hd][f][v]: one head's frame is 6208 contiguous bytes
+                        *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * NH + hd) * DV + col]) =
                             make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
                 }
             }

@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
                                                         const float* __restrict__ c0, float* __restrict__ hN,
                                                         float* __restrict__ cN, float* __restrict__ out, int nseq,
                                                         int nstep, int sdiv, int so, int si, int ps, int dir,
-                                                        int accumulate) {
+                                                        int accumulate, int dephase) {
     constexpr int NS = 16 * MT;
     constexpr int LSP = C + 4;
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
@@ -431,6 +431,14 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     const int q = tid & 15;
     const int unit = wave * 16 + l15;
     constexpr float INV = 1.0f / SPLIT_SCALE;
+    // The two workgroups sharing a CU start together and, with fair issue arbitration, stay phase-locked: both in the
+    // MFMA phase, then both in the activation (VALU) phase, so the matrix and vector pipes never overlap.  Giving the
+    // wave in the odd hardware slot a higher issue priority breaks the symmetry: it wins the MFMA pipe, reaches its
+    // VALU phase first, and from then on one workgroup's MFMAs run under the other's activations.
+    if (dephase) {
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID[3:0] = wave slot
+        if (hw_id & 1) __builtin_amdgcn_s_setprio(2);
+    }
 
     auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
     {
@@ -637,13 +645,15 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     }
 }
 
+static int g_dephase = 1;          // lh_set_tuning(3, 0) switches the slot-parity issue priority off (A/B runs)
 template <int MT>
 static int launch_lstm_lin(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                            const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep,
                            int sdiv, int so, int si, int ps, int dir, int accumulate, hipStream_t st) {
     constexpr int NS = 16 * MT;
     hipLaunchKernelGGL((k_ln_lstm_lin<MT>), dim3((nseq + NS - 1) / NS), dim3(256), 0, st, x, (const _Float16*)w_pk, b_sum,
-                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate);
+                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate,
+                       g_dephase);
     return check_launch();
 }
 
@@ -1092,6 +1102,7 @@ static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter M
 extern "C" int lh_set_tuning(int key, int value) {
     if (key < 0 || key >= 4) return LH_ERR_ARG;
     lh::g_tune[key] = value;
+    if (key == 3) lh::g_dephase = value;
     return LH_OK;
 }
 

@@ -156,6 +156,14 @@ __device__ __forceinline__ void frame_load(const float* __restrict__ src, int ti
         stg[i] = *reinterpret_cast<const float4*>(&src[(e >> 4) * C + (e & 15) * 4]);
     }
 }
+// same, from the attention kernel's head-major frame [4 heads][97][16]: channel c = head*16 + v
+__device__ __forceinline__ void frame_load_heads(const float* __restrict__ src, int tid, float4 (&stg)[FR_NLD]) {
+#pragma unroll
+    for (int i = 0; i < FR_NLD; ++i) {
+        const int e = min(tid + 256 * i, NF * 16 - 1);
+        stg[i] = *reinterpret_cast<const float4*>(&src[((e & 15) >> 2) * DV + (e >> 4) * VD + (e & 3) * 4]);
+    }
+}
 __device__ __forceinline__ void frame_store(_Float16* ahi, _Float16* alo, int tid, const float4 (&stg)[FR_NLD]) {
 #pragma unroll
     for (int i = 0; i < FR_NLD; ++i) {
@@ -299,13 +307,13 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
 
     frame_zero_pad(ahi, alo, tid);
     float4 stg[FR_NLD];
-    if ((int)blockIdx.x < nframes) frame_load(merged + (long)blockIdx.x * N, tid, stg);
+    if ((int)blockIdx.x < nframes) frame_load_heads(merged + (long)blockIdx.x * N, tid, stg);
     for (int fidx = blockIdx.x; fidx < nframes; fidx += gridDim.x) {     // grid-stride over frames (b*T + t)
         const int b = fidx / T;
         const long fr = (long)fidx * N;
         frame_store(ahi, alo, tid, stg);
         __syncthreads();                      // image complete; also orders the previous frame's reads of `ys`
-        if (fidx + (int)gridDim.x < nframes) frame_load(merged + (long)(fidx + gridDim.x) * N, tid, stg);
+        if (fidx + (int)gridDim.x < nframes) frame_load_heads(merged + (long)(fidx + gridDim.x) * N, tid, stg);
 
         // residual rows of this frame: loads in flight during the MFMA + statistics phases
         float4 rv[NSLOT];

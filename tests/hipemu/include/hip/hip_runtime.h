@@ -330,6 +330,7 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, in
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_getreg(x) (0u)
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
