@@ -44,7 +44,8 @@ enum { LH_GEMM_F32 = 0, LH_GEMM_F16X3 = 1 };
 int lh_abi_version(void);
 
 /* Launch-shape tuning knobs (benchmark A/B only; 0 = automatic): key 0 = sequences-per-workgroup/16 of the
- * intra LSTM, key 1 = same for the inter LSTM. */
+ * intra LSTM, key 1 = same for the inter LSTM, key 3 = 0 switches off the issue-priority de-phasing of the two
+ * workgroups that share a CU in the fused recurrent kernels (default on). */
 int lh_set_tuning(int key, int value);
 
 /* Validates model_params (reference net.py:21-49 / configs/tsh.json:5-19) against the compiled constants. */
@@ -108,15 +109,6 @@ int lh_intra_block(const float* x, const void* w_pk, const float* b_sum, const v
 int lh_inter_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                    const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,
                    lh_stream_t stream);
-
-/* Same contracts as lh_intra_block / lh_inter_block on the 8-wave kernel (gate columns split over eight waves, four
- * waves per SIMD); w8_pk = fp16 hi/lo image [dirs][8 waves][2 tiles][4 ksteps][64 lanes][16] (weights.py
- * pack_lstm8_f16x3). */
-int lh_intra_block8(const float* x, const void* w8_pk, const float* b_sum, const void* wlin_pk, const float* blin,
-                    float* out, int n_frames, lh_stream_t stream);
-int lh_inter_block8(const float* x, const void* w8_pk, const float* b_sum, const void* wlin_pk, const float* blin,
-                    const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,
-                    lh_stream_t stream);
 
 /* Row-wise Linear(K->64) + bias + residual:  out[r][:] = res[r][:] + W h[r][:] + b.
  * Replaces intra_linear + residual (tfgridnet_causal.py:513-516, K=128) and inter_linear + view/transpose +

@@ -11,6 +11,7 @@
 //   * exact fp32 MFMA (bitwise an fmaf chain) keeps the 625-step recurrences inside the 1e-3 budget;
 //   * x_{t+1} is fetched and normalised while step t computes; h_t is written back coalesced from LDS.
 #include "lh_common.h"
+#include <type_traits>
 
 namespace lh {
 
@@ -358,10 +359,10 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float ig = sigmoid_f(gate[m][0][r]);
-                const float fg = sigmoid_f(gate[m][1][r]);
-                const float gg = tanh_f(gate[m][2][r]);
-                const float og = sigmoid_f(gate[m][3][r]);
+                const float ig = sigmoid_pre(gate[m][0][r]);
+                const float fg = sigmoid_pre(gate[m][1][r]);
+                const float gg = tanh_pre(gate[m][2][r]);
+                const float og = sigmoid_pre(gate[m][3][r]);
                 const float cc = fg * creg[m][r] + ig * gg;
                 creg[m][r] = cc;
                 const float hv = og * tanh_f(cc);
@@ -462,13 +463,19 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + unit];
 
-        auto load_x = [&](int it, float4 (&xr)[MT]) {
-            const int p = step_pos(it);
+        // element offset of this thread's float4 in its row(s) at step position 0 (loop-invariant, per thread) — the
+        // step-dependent part p * ps * C is wave-uniform and stays in scalar registers
+        long toff[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
-                xr[i] = *reinterpret_cast<const float4*>(&x[row_of(s, p) * C + q * 4]);
-            }
+        for (int i = 0; i < MT; ++i) {
+            const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);    // tail rows replicate sequence nseq-1
+            toff[i] = row_of(s, 0) * C + q * 4;
+        }
+        auto uoff = [&](int it) -> long { return (long)step_pos(it) * ps * C; };
+        auto load_x = [&](int it, float4 (&xr)[MT]) {
+            const long u = uoff(it);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xr[i] = *reinterpret_cast<const float4*>(&x[toff[i] + u]);
         };
         auto store_split4 = [&](int buf, int rl, int col, float a, float b, float c, float d) {
             f16x4 h4, l4;
@@ -494,24 +501,20 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
         };
         // base of the projection's accumulation for the rows of step `it`: pass 0 the residual (= the un-normalised
         // LSTM input itself), pass 1 the partial sum written by pass 0 (same thread, same rows)
+        const float* base_src = accumulate ? out : x;
         auto load_base = [&](int it, float4 (&rr)[MT]) {
-            const int p = step_pos(it);
+            const long u = uoff(it);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
-                const float* src = accumulate ? out : x;
-                rr[i] = *reinterpret_cast<const float4*>(&src[row_of(s, p) * C + q * 4]);
-            }
+            for (int i = 0; i < MT; ++i) rr[i] = *reinterpret_cast<const float4*>(&base_src[toff[i] + u]);
         };
         // finished rows of step `it`: base + (bias) + projection parked in ls[buf]
         auto store_rows = [&](int it, int buf, const float4 (&rr)[MT]) {
-            const int p = step_pos(it);
+            const long u = uoff(it);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int rl = (tid + 256 * i) >> 4;
-                const int s = min(s0 + rl, nseq - 1);        // tail rows replicate sequence nseq-1: identical bytes
+                const int rl = (tid + 256 * i) >> 4;         // tail rows replicate sequence nseq-1: identical bytes
                 const float4 pv = *reinterpret_cast<const float4*>(&ls[(buf * NS + rl) * LSP + q * 4]);
-                *reinterpret_cast<float4*>(&out[row_of(s, p) * C + q * 4]) =
+                *reinterpret_cast<float4*>(&out[toff[i] + u]) =
                     make_float4(rr[i].x + pv.x, rr[i].y + pv.y, rr[i].z + pv.z, rr[i].w + pv.w);
             }
         };
@@ -563,10 +566,12 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
         }
         __syncthreads();
 
-        for (int it = 0; it < nstep; ++it) {
-            const int cur = it & 1, nxt = cur ^ 1;
+        // one step; the buffer parity CUR = it & 1 is a compile-time constant (the loop below is unrolled by two), so
+        // every LDS address is a loop-invariant base plus an immediate
+        auto step = [&](int it, auto CURC) {
+            constexpr int cur = decltype(CURC)::value, nxt = cur ^ 1;
             // rows of step it-2 are complete: projection parked in ls[(it-1)&1] one step ago, base fetched one step ago
-            if (it >= 2) store_rows(it - 2, (it - 1) & 1, rr);
+            if (it >= 2) store_rows(it - 2, nxt, rr);
             load_base(it - 1, rr);                        // consumed next iteration (clamped at it = 0: unused)
             norm_store_x(nxt, xr);
             load_x(it + 2, xr);
@@ -595,16 +600,16 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
 #pragma unroll
                 for (int g = 0; g < 4; ++g) gate[m][g] = accm[g] + accc[g] * INV;
             }
-            lin_tile(cur, it & 1);                        // projection of h_{it-1} (at it = 0: of the initial state, unused)
+            lin_tile(cur, cur);                           // projection of h_{it-1} (at it = 0: of the initial state, unused)
 
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float ig = sigmoid_f(gate[m][0][r]);
-                    const float fg = sigmoid_f(gate[m][1][r]);
-                    const float gg = tanh_f(gate[m][2][r]);
-                    const float og = sigmoid_f(gate[m][3][r]);
+                    const float ig = sigmoid_pre(gate[m][0][r]);
+                    const float fg = sigmoid_pre(gate[m][1][r]);
+                    const float gg = tanh_pre(gate[m][2][r]);
+                    const float og = sigmoid_pre(gate[m][3][r]);
                     const float cc = fg * creg[m][r] + ig * gg;
                     creg[m][r] = cc;
                     const float hv = og * tanh_f(cc);
@@ -616,6 +621,14 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
                     hf[rl * LSP + unit] = hv;
                 }
             __syncthreads();
+        };
+        {
+            int it = 0;
+            for (; it + 1 < nstep; it += 2) {
+                step(it, std::integral_constant<int, 0>{});
+                step(it + 1, std::integral_constant<int, 1>{});
+            }
+            if (it < nstep) step(it, std::integral_constant<int, 0>{});
         }
 
         // ---- drain: rows of the last two steps
@@ -657,411 +670,6 @@ static int launch_lstm_lin(const float* x, const void* w_pk, const float* b_sum,
     return check_launch();
 }
 
-// ------------------------------------------------------------------------------------------------------
-// 8-wave variant of the fused recurrence ("lstm8"): the 256 gate columns are split over EIGHT waves (wave w owns
-// hidden units 8w..8w+7: column tile A = [i | f], tile B = [g | o] of those units), so a wave keeps only 64
-// registers of weight fragments instead of 128 and FOUR waves fit on every SIMD (2 workgroups x 8 waves per CU).
-// The recurrence is latency-bound (barrier -> LDS -> 24 MFMAs -> exp/rcp chain -> LDS -> barrier); twice the
-// resident waves hide twice the latency.  i/f and g/o of a unit land in lanes l and l ^ 8 of a 16-lane row: one
-// DPP row rotation swaps what each half needs, after which every lane finishes two (sequence, unit) cells.
-// Waves 0-3 also stage/normalise the next input rows, waves 4-7 run the output projection and the row epilogue.
-// ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512, 4) k_lstm8(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
-                                                  const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
-                                                  const float* __restrict__ blin, const float* __restrict__ h0,
-                                                  const float* __restrict__ c0, float* __restrict__ hN,
-                                                  float* __restrict__ cN, float* __restrict__ out, int nseq, int nstep,
-                                                  int sdiv, int so, int si, int ps, int dir, int accumulate) {
-    constexpr int NS = 16;
-    constexpr int LSP = C + 4;
-    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
-    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
-    __shared__ __attribute__((aligned(16))) float ls[2 * NS * LSP];
-    __shared__ __attribute__((aligned(16))) float hf[NS * LSP];
-    __shared__ __attribute__((aligned(16))) _Float16 wls[4 * 2 * 64 * 16];        // output-projection B image
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s0 = blockIdx.x * NS;
-    const int g4 = lane >> 4, l15 = lane & 15, half = l15 >> 3, u8 = l15 & 7;
-    for (int i = tid; i < 4 * 2 * 64 * 2; i += 512)
-        *reinterpret_cast<f16x8*>(&wls[i * 8]) = *reinterpret_cast<const f16x8*>(&wlin_pk[i * 8]);
-    const int unit = wave * 8 + u8;
-    const int t2 = tid & 255, rl = t2 >> 4, q = t2 & 15;         // row-wise role (waves 0-3: x rows, waves 4-7: out rows)
-    const int sr = min(s0 + rl, nseq - 1);
-    const bool xrole = wave < 4;
-    constexpr float INV = 1.0f / SPLIT_SCALE;
-
-    auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
-    auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
-
-    // resident gate weights: image [dir][wave 8][tile 2][ks 4][lane][hi8|lo8]
-    f16x8 wh[2][4], wl[2][4];
-    {
-        const _Float16* wp = w_pk + ((long)(dir * 8 + wave) * 8 * 64 + lane) * 16;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                wh[t][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(t * 4 + ks) * 64 * 16);
-                wl[t][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(t * 4 + ks) * 64 * 16 + 8);
-            }
-    }
-    const float biasA = b_sum[dir * 256 + half * 64 + unit];             // i (half 0) / f (half 1)
-    const float biasB = b_sum[dir * 256 + (2 + half) * 64 + unit];       // g / o
-    const float lbias = accumulate ? 0.0f : blin[((wave & 3) << 4) + l15];
-
-    auto store_split4 = [&](int buf, int row, int col, float a, float b, float c, float d) {
-        f16x4 h4, l4;
-        _Float16 th, tl;
-        split_f16(a, th, tl); h4[0] = th; l4[0] = tl;
-        split_f16(b, th, tl); h4[1] = th; l4[1] = tl;
-        split_f16(c, th, tl); h4[2] = th; l4[2] = tl;
-        split_f16(d, th, tl); h4[3] = th; l4[3] = tl;
-        *reinterpret_cast<f16x4*>(&ahi[(buf * NS + row) * LH_AP + col]) = h4;
-        *reinterpret_cast<f16x4*>(&alo[(buf * NS + row) * LH_AP + col]) = l4;
-    };
-    auto load_x = [&](int it) -> float4 { return *reinterpret_cast<const float4*>(&x[row_of(sr, step_pos(it)) * C + q * 4]); };
-    auto norm_store_x = [&](int buf, float4 v) {
-        const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
-        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-        const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
-        const float rstd = rsqrtf(var + LN_EPS);
-        store_split4(buf, rl, q * 4, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
-    };
-    auto load_base = [&](int it) -> float4 {
-        const float* src = accumulate ? out : x;
-        return *reinterpret_cast<const float4*>(&src[row_of(sr, step_pos(it)) * C + q * 4]);
-    };
-    auto store_rows = [&](int it, int buf, float4 rr) {
-        const float4 pv = *reinterpret_cast<const float4*>(&ls[(buf * NS + rl) * LSP + q * 4]);
-        *reinterpret_cast<float4*>(&out[row_of(sr, step_pos(it)) * C + q * 4]) =
-            make_float4(rr.x + pv.x, rr.y + pv.y, rr.z + pv.z, rr.w + pv.w);
-    };
-    // waves 4-7: projection tile (wave & 3) of the h tile in A buffer `buf` -> ls[lbuf]
-    auto lin_tile = [&](int buf, int lbuf) {
-        const int nt = wave & 3;
-        f32x4 am = f32x4{lbias, lbias, lbias, lbias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ro = (buf * NS + l15) * LH_AP + g4 * 8;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const _Float16* wp = &wls[((nt * 2 + ks) * 64 + lane) * 16];
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(wp);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(wp + 8);
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + (2 + ks) * 32]);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + (2 + ks) * 32]);
-            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, am, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, ac, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ls[(lbuf * NS + g4 * 4 + r) * LSP + nt * 16 + l15] = am[r] + ac[r] * INV;
-    };
-
-    // ---- prologue
-    float creg[2];
-    float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);     // x role: next input row; out role: base of the row being finished
-    if (xrole) {
-        norm_store_x(0, load_x(0));
-        rw = load_x(1);
-    } else {
-        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)sr * H + q * 4]);
-        store_split4(0, rl, C + q * 4, hv.x, hv.y, hv.z, hv.w);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int s = min(s0 + g4 * 4 + half * 2 + j, nseq - 1);
-        creg[j] = c0 ? c0[(long)s * H + unit] : 0.0f;
-    }
-    __syncthreads();
-
-    for (int it = 0; it < nstep; ++it) {
-        const int cur = it & 1, nxt = cur ^ 1;
-        if (xrole) {                                  // wave-uniform role split
-            norm_store_x(nxt, rw);
-            rw = load_x(it + 2);
-        } else {
-            if (it >= 2) store_rows(it - 2, (it - 1) & 1, rw);
-            rw = load_base(it - 1);
-        }
-
-        f32x4 am[2], ac[2];
-        am[0] = f32x4{biasA, biasA, biasA, biasA}; am[1] = f32x4{biasB, biasB, biasB, biasB};
-        ac[0] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ro = (cur * NS + l15) * LH_AP + g4 * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) am[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[t][ks], am[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[t][ks], ac[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[t][ks], ac[t], 0, 0, 0);
-            // keep at most one k-step of A fragments in flight: with four waves per SIMD the LDS latency is covered by
-            // the other waves, and the 128-register budget has no room for deeper prefetch
-            if (ks & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        const f32x4 gA = am[0] + ac[0] * INV, gB = am[1] + ac[1] * INV;
-        if (!xrole) lin_tile(cur, it & 1);            // projection of h_{it-1} (at it = 0: of the initial state, unused)
-
-        // lanes l (i, g of rows 0..3) and l ^ 8 (f, o of rows 0..3) trade two rows each: afterwards the low half owns
-        // rows 0,1 and the high half rows 2,3 with all four gates
-        const float sA0 = half ? gA[0] : gA[2], sA1 = half ? gA[1] : gA[3];
-        const float sB0 = half ? gB[0] : gB[2], sB1 = half ? gB[1] : gB[3];
-        const float rA[2] = {row_ror_mov<8>(sA0), row_ror_mov<8>(sA1)};
-        const float rB[2] = {row_ror_mov<8>(sB0), row_ror_mov<8>(sB1)};
-        const float mA[2] = {half ? gA[2] : gA[0], half ? gA[3] : gA[1]};
-        const float mB[2] = {half ? gB[2] : gB[0], half ? gB[3] : gB[1]};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float ig = sigmoid_f(half ? rA[j] : mA[j]);
-            const float fg = sigmoid_f(half ? mA[j] : rA[j]);
-            const float gg = tanh_f(half ? rB[j] : mB[j]);
-            const float og = sigmoid_f(half ? mB[j] : rB[j]);
-            const float cc = fg * creg[j] + ig * gg;
-            creg[j] = cc;
-            const float hv = og * tanh_f(cc);
-            const int row = g4 * 4 + half * 2 + j;
-            _Float16 th, tl;
-            split_f16(hv, th, tl);
-            ahi[(nxt * NS + row) * LH_AP + C + unit] = th;
-            alo[(nxt * NS + row) * LH_AP + C + unit] = tl;
-            hf[row * LSP + unit] = hv;
-        }
-        __syncthreads();
-    }
-
-    // ---- drain: rows of the last two steps, final state
-    if (!xrole) {
-        if (nstep >= 2) store_rows(nstep - 2, (nstep - 1) & 1, rw);
-        rw = load_base(nstep - 1);
-        lin_tile(nstep & 1, nstep & 1);
-    }
-    __syncthreads();
-    if (!xrole) {
-        store_rows(nstep - 1, nstep & 1, rw);
-        if (hN && s0 + rl < nseq)
-            *reinterpret_cast<float4*>(&hN[(long)(s0 + rl) * H + q * 4]) = *reinterpret_cast<const float4*>(&hf[rl * LSP + q * 4]);
-    }
-    if (cN) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int s = s0 + g4 * 4 + half * 2 + j;
-            if (s < nseq) cN[(long)s * H + unit] = creg[j];
-        }
-    }
-}
-
-static int launch_lstm8(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
-                        const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep, int sdiv,
-                        int so, int si, int ps, int dir, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(k_lstm8, dim3((nseq + 15) / 16), dim3(512), 0, st, x, (const _Float16*)w_pk, b_sum,
-                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate);
-    return check_launch();
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Software-pipelined split-precision kernel (NS = 16 sequences per workgroup): the gate pre-activations are
-//     gates_t = [LN(x_t) W_ih^T + b]  +  h_{t-1} W_hh^T
-// and only the second term sits on the recurrence.  The x-term of step t+1 is computed inside step t, in the
-// same basic block as the cell update of step t, so its 24 MFMAs run on the matrix pipe underneath the ~190
-// VALU instructions (exp/rcp/LayerNorm/splits) of the cell update; the post-barrier critical path of a step
-// shrinks to: read h fragments -> 24 MFMAs -> cell update -> write h.  x tiles are triple-buffered (tile t+2
-// is normalised and written while tile t+1 is consumed), LDS images use the swizzled block layout of
-// lh_common.h (conflict-free fragment reads and row-major writes).
-// ------------------------------------------------------------------------------------------------------
-constexpr int LP_RP = 16;                        // rows per A image
-constexpr int LP_XI = 2 * 4 * LP_RP * 8;         // halves per x (or h) image: K = 64 -> 2 k-steps x 4 lane groups
-
-__device__ __forceinline__ int lp_slot(int blk, int row) { return (blk * LP_RP + (row ^ (blk & 7))) * 8; }
-__device__ __forceinline__ int lp_index(int row, int k) { return lp_slot((k >> 5) * 4 + ((k >> 3) & 3), row) + (k & 7); }
-
-__global__ void __launch_bounds__(256, 2) k_ln_lstm_p(const float* __restrict__ x, const float* __restrict__ lnw,
-                                                      const float* __restrict__ lnb, const _Float16* __restrict__ w_pk,
-                                                      const float* __restrict__ b_sum, const float* __restrict__ h0,
-                                                      const float* __restrict__ c0, float* __restrict__ hN,
-                                                      float* __restrict__ cN, float* __restrict__ h_out, int nseq,
-                                                      int nstep, int sdiv, int so, int si, int ps, int ldh) {
-    constexpr int NS = 16;
-    __shared__ __attribute__((aligned(16))) _Float16 xhi[3 * LP_XI], xlo[3 * LP_XI];
-    __shared__ __attribute__((aligned(16))) _Float16 hhi[2 * LP_XI], hlo[2 * LP_XI];
-    __shared__ __attribute__((aligned(16))) float hf[2 * NS * LH_HP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dir = blockIdx.y;
-    const int s0 = blockIdx.x * NS;
-    const int g4 = lane >> 4, l15 = lane & 15;
-
-    auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
-    auto step_pos = [&](int it) -> int { it = min(it, nstep - 1); return dir ? (nstep - 1 - it) : it; };
-
-    // resident weights, image [dir][wave][gate][ks][lane][hi8|lo8]; ks 0,1 = W_ih (x), ks 2,3 = W_hh (h)
-    f16x8 wh[4][4], wl[4][4];
-    {
-        const _Float16* wp = w_pk + ((long)(dir * 4 + wave) * 16 * 64 + lane) * 16;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                wh[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16);
-                wl[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16 + 8);
-            }
-    }
-    float bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + wave * 16 + l15];
-
-    // row-wise role: 16 lanes per 64-float row, one float4 each
-    const int q = tid & 15, rl = tid >> 4;
-    const int sr = min(s0 + rl, nseq - 1);
-    // the LayerNorm affine is folded into the packed image: W_ih' = W_ih * ln_w, b' = b + W_ih ln_b (weights.py)
-
-    auto load_x = [&](int it) -> float4 {
-        return *reinterpret_cast<const float4*>(&x[row_of(sr, step_pos(it)) * C + q * 4]);
-    };
-    auto store_split = [&](_Float16* phi, _Float16* plo, int row, int k0, float a, float b, float c, float d) {
-        const float v[4] = {a, b, c, d};
-        f16x4 h4, l4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const _Float16 th = (_Float16)v[i];
-            h4[i] = th;
-            l4[i] = (_Float16)((v[i] - (float)th) * SPLIT_SCALE);
-        }
-        const int idx = lp_index(row, k0);
-        *reinterpret_cast<f16x4*>(&phi[idx]) = h4;
-        *reinterpret_cast<f16x4*>(&plo[idx]) = l4;
-    };
-    auto norm_store_x = [&](int buf, float4 v) {
-        const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
-        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-        const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
-        const float rstd = rsqrtf(var + LN_EPS);
-        store_split(xhi + buf * LP_XI, xlo + buf * LP_XI, rl, q * 4, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
-    };
-    // gates_x = bias + LN(x) W_ih^T for the tile in x buffer `buf` (24 MFMAs, no dependence on the recurrence)
-    auto x_gates = [&](int buf, f32x4 (&gx)[4]) {
-        f32x4 am[4], ac[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            am[g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
-            ac[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int idx = buf * LP_XI + lp_slot(ks * 4 + g4, l15);
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(&xhi[idx]);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(&xlo[idx]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) am[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], am[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], ac[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], ac[g], 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gx[g] = am[g] + ac[g] * (1.0f / SPLIT_SCALE);
-    };
-    auto flush_h = [&](int buf, int it) {          // fp32 h of step `it` -> global, coalesced 256-byte rows
-        if (s0 + rl < nseq)
-            *reinterpret_cast<float4*>(&h_out[row_of(s0 + rl, step_pos(it)) * ldh + dir * H + q * 4]) =
-                *reinterpret_cast<const float4*>(&hf[(buf * NS + rl) * LH_HP + q * 4]);
-    };
-
-    // ---- prologue: x tiles 0 and 1, initial state, gates_x of step 0
-    float creg[4];
-    {
-        norm_store_x(0, load_x(0));
-        norm_store_x(1, load_x(1));
-        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)sr * H + q * 4]);
-        store_split(hhi, hlo, rl, q * 4, hv.x, hv.y, hv.z, hv.w);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = min(s0 + g4 * 4 + r, nseq - 1);
-            creg[r] = c0 ? c0[(long)s * H + wave * 16 + l15] : 0.0f;
-        }
-    }
-    __syncthreads();
-    f32x4 gx[4];
-    x_gates(0, gx);
-    float4 xr = load_x(2);
-
-    const int unit = wave * 16 + l15;
-    for (int it = 0; it < nstep; ++it) {
-        const int cur = it & 1, nxt = cur ^ 1;
-        if (it > 0) flush_h(cur, it - 1);
-
-        // recurrent term: h_{t-1} W_hh^T on top of the precomputed gates_x (k-steps 2,3 of the weight image)
-        f32x4 am[4], ac[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { am[g] = gx[g]; ac[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int idx = cur * LP_XI + lp_slot(ks * 4 + g4, l15);
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(&hhi[idx]);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(&hlo[idx]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) am[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][2 + ks], am[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][2 + ks], ac[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ac[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][2 + ks], ac[g], 0, 0, 0);
-        }
-
-        // gates_x of step t+1 (tile written one step ago): independent MFMAs the scheduler can sink under the
-        // VALU work below.  After the last step the tile is stale but finite and the result is unused.
-        f32x4 gxn[4];
-        x_gates((it + 1) % 3, gxn);
-
-        // cell update, lane-local: accumulator reg r <-> sequence row g4*4 + r, hidden unit wave*16 + l15
-        constexpr float INV = 1.0f / SPLIT_SCALE;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ig = sigmoid_f(am[0][r] + ac[0][r] * INV);
-            const float fg = sigmoid_f(am[1][r] + ac[1][r] * INV);
-            const float gg = tanh_f(am[2][r] + ac[2][r] * INV);
-            const float og = sigmoid_f(am[3][r] + ac[3][r] * INV);
-            const float cc = fg * creg[r] + ig * gg;
-            creg[r] = cc;
-            const float hv = og * tanh_f(cc);
-            const int row = g4 * 4 + r;
-            const _Float16 th = (_Float16)hv;
-            const int idx = nxt * LP_XI + lp_index(row, unit);
-            hhi[idx] = th;
-            hlo[idx] = (_Float16)((hv - (float)th) * SPLIT_SCALE);
-            hf[(nxt * NS + row) * LH_HP + unit] = hv;
-        }
-        // x tile of step t+2, then fetch the row of step t+3 (clamped past the end: harmless rewrites)
-        norm_store_x((it + 2) % 3, xr);
-        xr = load_x(it + 3);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gx[g] = gxn[g];
-        __syncthreads();
-    }
-
-    const int last = nstep & 1;
-    flush_h(last, nstep - 1);
-    if (hN && s0 + rl < nseq)
-        *reinterpret_cast<float4*>(&hN[(long)(s0 + rl) * H + q * 4]) =
-            *reinterpret_cast<const float4*>(&hf[(last * NS + rl) * LH_HP + q * 4]);
-    if (cN) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = s0 + g4 * 4 + r;
-            if (s < nseq) cN[(long)s * H + wave * 16 + l15] = creg[r];
-        }
-    }
-}
-
-static int launch_lstm_p(const float* x, const float* lnw, const float* lnb, const void* w_pk, const float* b_sum,
-                         const float* h0, const float* c0, float* hN, float* cN, float* h_out, int nseq, int nstep,
-                         int ndir, int sdiv, int so, int si, int ps, int ldh, hipStream_t st) {
-    hipLaunchKernelGGL(k_ln_lstm_p, dim3((nseq + 15) / 16, ndir), dim3(256), 0, st, x, lnw, lnb, (const _Float16*)w_pk,
-                       b_sum, h0, c0, hN, cN, h_out, nseq, nstep, sdiv, so, si, ps, ldh);
-    return check_launch();
-}
-
 template <int MT>
 static int launch_lstm_h3(const float* x, const float* lnw, const float* lnb, const void* w_pk, const float* b_sum,
                           const float* h0, const float* c0, float* hN, float* cN, float* h_out, int nseq, int nstep,
@@ -1097,7 +705,7 @@ static int cu_count() {
     }
     return n;
 }
-static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [2] 1 = software-pipelined f16x3 kernel (experimental, slower)
+static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [3] 0 = no issue-priority de-phasing
 }
 extern "C" int lh_set_tuning(int key, int value) {
     if (key < 0 || key >= 4) return LH_ERR_ARG;
@@ -1114,9 +722,6 @@ extern "C" int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* 
     const int mt = g_tune[0] ? g_tune[0] : (mode == LH_GEMM_F16X3 ? 0 : (n_frames >= 8192 ? 2 : 1));
     if (mode == LH_GEMM_F16X3) {
         hipStream_t st = (hipStream_t)stream;
-        if (mt == 1 && g_tune[2] == 1)
-            return launch_lstm_p(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF, 2, 1,
-                                 NF, 0, 1, 2 * H, st);
         if (mt == 2)
             return launch_lstm_h3<2>(x, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out, n_frames, NF,
                                      2, 1, NF, 0, 1, 2 * H, st);
@@ -1158,9 +763,6 @@ extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* 
     const int nseq = B * NF;
     const int mt = g_tune[1] ? g_tune[1] : (nseq >= 32768 ? 2 : 1);
     if (mode == LH_GEMM_F16X3) {
-        if (mt == 1 && g_tune[2] == 1)
-            return launch_lstm_p(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
-                                 (hipStream_t)stream);
         if (mt == 2)
             return launch_lstm_h3<2>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,
                                      (hipStream_t)stream);
@@ -1198,26 +800,4 @@ extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_s
     if (h0 == hN || c0 == cN || x == out) return LH_ERR_ARG;
     return launch_lstm_lin<1>(x, w_pk, b_sum, wlin_pk, blin, h0, c0, hN, cN, out, B * NF, T, NF, T * NF, 1, NF, 0, 0,
                               (hipStream_t)stream);
-}
-
-// 8-wave fused kernels (weights image of weights.py pack_lstm8_f16x3)
-extern "C" int lh_intra_block8(const float* x, const void* w8_pk, const float* b_sum, const void* wlin_pk,
-                               const float* blin, float* out, int n_frames, lh_stream_t stream) {
-    using namespace lh;
-    if (!x || !w8_pk || !b_sum || !wlin_pk || !blin || !out || n_frames <= 0 || x == out) return LH_ERR_ARG;
-    int rc = LH_OK;
-    for (int dir = 0; dir < 2 && rc == LH_OK; ++dir)
-        rc = launch_lstm8(x, w8_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, nullptr, nullptr,
-                          nullptr, nullptr, out, n_frames, NF, 1, NF, 0, 1, dir, dir, (hipStream_t)stream);
-    return rc;
-}
-
-extern "C" int lh_inter_block8(const float* x, const void* w8_pk, const float* b_sum, const void* wlin_pk,
-                               const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out,
-                               int B, int T, lh_stream_t stream) {
-    using namespace lh;
-    if (!x || !w8_pk || !b_sum || !wlin_pk || !blin || !h0 || !c0 || !hN || !cN || !out || B <= 0 || T <= 0) return LH_ERR_ARG;
-    if (h0 == hN || c0 == cN || x == out) return LH_ERR_ARG;
-    return launch_lstm8(x, w8_pk, b_sum, wlin_pk, blin, h0, c0, hN, cN, out, B * NF, T, NF, T * NF, 1, NF, 0, 0,
-                        (hipStream_t)stream);
 }

@@ -151,9 +151,6 @@ class Net(nn.Module):
         self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
-        # fused recurrence kernel flavour: 4 = four waves x 64 gate columns (default); 8 = experimental eight-wave split
-        # (four waves per SIMD) that measured 1.4-1.6x slower on MI355X (register spills, wider barrier), kept for A/B
-        self.lstm_waves = int(os.environ.get("LOOKONCE_LSTM_WAVES", "4"))
         self.fuse_intra_min_frames = 8192
         self._pack_key = None
         self._packed = None
@@ -303,22 +300,15 @@ class Net(nn.Module):
                 # the forward one's rows): worth it once a single direction fills the GPU, otherwise the unfused kernel
                 # (both directions concurrently) has half the latency (streaming, batch 1)
                 if fuse and Bn * T >= self.fuse_intra_min_frames:
-                    if self.lstm_waves == 8:
-                        lib.call("lh_intra_block8", P(xa), P(bp["intra_w8"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
-                                 P(bp["intra_lin_b"]), P(xb), Bn * T, st)
-                    else:
-                        lib.call("lh_intra_block", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
-                                 P(bp["intra_lin_b"]), P(xb), Bn * T, st)
+                    lib.call("lh_intra_block", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
+                             P(bp["intra_lin_b"]), P(xb), Bn * T, st)
                 else:
                     # intra: LN + BiLSTM over frequency -> Linear(128->64) + residual
                     lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra" + wkey]),
                              P(bp["intra" + bkey]), P(hbuf), Bn * T, mode, st)
                     lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
                              2 * H_, st)
-                if fuse and self.lstm_waves == 8:
-                    lib.call("lh_inter_block8", P(xb), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
-                             P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
-                elif fuse:
+                if fuse:
                     lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
                              P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
                 else:
