@@ -78,5 +78,6 @@ def load() -> Lib:
     """The gfx950 library (cached). Raises if it has not been built."""
     global _hip_lib
     if _hip_lib is None:
-        _hip_lib = Lib(HIP_LIB_PATH)
+        # LOOKONCE_HIP_LIB: another build of the same ABI (A/B timing of kernel revisions inside one gpurun call)
+        _hip_lib = Lib(os.environ.get("LOOKONCE_HIP_LIB", HIP_LIB_PATH))
     return _hip_lib

@@ -38,10 +38,6 @@ __device__ __forceinline__ float sigmoid_f(float x) {
 __device__ __forceinline__ float tanh_f(float x) {
     return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * LOG2E * x)) - 1.0f;
 }
-// the same with the argument scale folded into the packed weights (weights.py gate_prescale):
-// t = -log2(e) v for sigmoid, t = -2 log2(e) v for tanh
-__device__ __forceinline__ float sigmoid_pre(float t) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t)); }
-__device__ __forceinline__ float tanh_pre(float t) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t)) - 1.0f; }
 __device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
 
 // sum over the 64 lanes of a wave (every lane gets the total): 4 DPP row steps + 2 cross-row shuffles

@@ -11,7 +11,6 @@
 //   * exact fp32 MFMA (bitwise an fmaf chain) keeps the 625-step recurrences inside the 1e-3 budget;
 //   * x_{t+1} is fetched and normalised while step t computes; h_t is written back coalesced from LDS.
 #include "lh_common.h"
-#include <type_traits>
 
 namespace lh {
 
@@ -359,10 +358,10 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float ig = sigmoid_pre(gate[m][0][r]);
-                const float fg = sigmoid_pre(gate[m][1][r]);
-                const float gg = tanh_pre(gate[m][2][r]);
-                const float og = sigmoid_pre(gate[m][3][r]);
+                const float ig = sigmoid_f(gate[m][0][r]);
+                const float fg = sigmoid_f(gate[m][1][r]);
+                const float gg = tanh_f(gate[m][2][r]);
+                const float og = sigmoid_f(gate[m][3][r]);
                 const float cc = fg * creg[m][r] + ig * gg;
                 creg[m][r] = cc;
                 const float hv = og * tanh_f(cc);
@@ -463,19 +462,13 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + unit];
 
-        // element offset of this thread's float4 in its row(s) at step position 0 (loop-invariant, per thread) — the
-        // step-dependent part p * ps * C is wave-uniform and stays in scalar registers
-        long toff[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);    // tail rows replicate sequence nseq-1
-            toff[i] = row_of(s, 0) * C + q * 4;
-        }
-        auto uoff = [&](int it) -> long { return (long)step_pos(it) * ps * C; };
         auto load_x = [&](int it, float4 (&xr)[MT]) {
-            const long u = uoff(it);
+            const int p = step_pos(it);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) xr[i] = *reinterpret_cast<const float4*>(&x[toff[i] + u]);
+            for (int i = 0; i < MT; ++i) {
+                const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
+                xr[i] = *reinterpret_cast<const float4*>(&x[row_of(s, p) * C + q * 4]);
+            }
         };
         auto store_split4 = [&](int buf, int rl, int col, float a, float b, float c, float d) {
             f16x4 h4, l4;
@@ -501,20 +494,24 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
         };
         // base of the projection's accumulation for the rows of step `it`: pass 0 the residual (= the un-normalised
         // LSTM input itself), pass 1 the partial sum written by pass 0 (same thread, same rows)
-        const float* base_src = accumulate ? out : x;
         auto load_base = [&](int it, float4 (&rr)[MT]) {
-            const long u = uoff(it);
+            const int p = step_pos(it);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) rr[i] = *reinterpret_cast<const float4*>(&base_src[toff[i] + u]);
+            for (int i = 0; i < MT; ++i) {
+                const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
+                const float* src = accumulate ? out : x;
+                rr[i] = *reinterpret_cast<const float4*>(&src[row_of(s, p) * C + q * 4]);
+            }
         };
         // finished rows of step `it`: base + (bias) + projection parked in ls[buf]
         auto store_rows = [&](int it, int buf, const float4 (&rr)[MT]) {
-            const long u = uoff(it);
+            const int p = step_pos(it);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int rl = (tid + 256 * i) >> 4;         // tail rows replicate sequence nseq-1: identical bytes
+                const int rl = (tid + 256 * i) >> 4;
+                const int s = min(s0 + rl, nseq - 1);        // tail rows replicate sequence nseq-1: identical bytes
                 const float4 pv = *reinterpret_cast<const float4*>(&ls[(buf * NS + rl) * LSP + q * 4]);
-                *reinterpret_cast<float4*>(&out[toff[i] + u]) =
+                *reinterpret_cast<float4*>(&out[row_of(s, p) * C + q * 4]) =
                     make_float4(rr[i].x + pv.x, rr[i].y + pv.y, rr[i].z + pv.z, rr[i].w + pv.w);
             }
         };
@@ -566,12 +563,10 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
         }
         __syncthreads();
 
-        // one step; the buffer parity CUR = it & 1 is a compile-time constant (the loop below is unrolled by two), so
-        // every LDS address is a loop-invariant base plus an immediate
-        auto step = [&](int it, auto CURC) {
-            constexpr int cur = decltype(CURC)::value, nxt = cur ^ 1;
+        for (int it = 0; it < nstep; ++it) {
+            const int cur = it & 1, nxt = cur ^ 1;
             // rows of step it-2 are complete: projection parked in ls[(it-1)&1] one step ago, base fetched one step ago
-            if (it >= 2) store_rows(it - 2, nxt, rr);
+            if (it >= 2) store_rows(it - 2, (it - 1) & 1, rr);
             load_base(it - 1, rr);                        // consumed next iteration (clamped at it = 0: unused)
             norm_store_x(nxt, xr);
             load_x(it + 2, xr);
@@ -600,16 +595,16 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
 #pragma unroll
                 for (int g = 0; g < 4; ++g) gate[m][g] = accm[g] + accc[g] * INV;
             }
-            lin_tile(cur, cur);                           // projection of h_{it-1} (at it = 0: of the initial state, unused)
+            lin_tile(cur, it & 1);                        // projection of h_{it-1} (at it = 0: of the initial state, unused)
 
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float ig = sigmoid_pre(gate[m][0][r]);
-                    const float fg = sigmoid_pre(gate[m][1][r]);
-                    const float gg = tanh_pre(gate[m][2][r]);
-                    const float og = sigmoid_pre(gate[m][3][r]);
+                    const float ig = sigmoid_f(gate[m][0][r]);
+                    const float fg = sigmoid_f(gate[m][1][r]);
+                    const float gg = tanh_f(gate[m][2][r]);
+                    const float og = sigmoid_f(gate[m][3][r]);
                     const float cc = fg * creg[m][r] + ig * gg;
                     creg[m][r] = cc;
                     const float hv = og * tanh_f(cc);
@@ -621,14 +616,6 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
                     hf[rl * LSP + unit] = hv;
                 }
             __syncthreads();
-        };
-        {
-            int it = 0;
-            for (; it + 1 < nstep; it += 2) {
-                step(it, std::integral_constant<int, 0>{});
-                step(it + 1, std::integral_constant<int, 1>{});
-            }
-            if (it < nstep) step(it, std::integral_constant<int, 0>{});
         }
 
         // ---- drain: rows of the last two steps

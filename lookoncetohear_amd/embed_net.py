@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _cabi
-from .weights import gate_prescale, pack_linear_f16x3, pack_mfma_f32, split_f16
+from .weights import pack_linear_f16x3, pack_mfma_f32, split_f16
 
 
 class _LN4D(nn.Module):
@@ -184,18 +184,17 @@ def _pack_axis(sd, pre, ax):
     (c*4 + k) to window-major (k*64 + c), output columns reordered to (direction, unit, gate)."""
     g = lambda k: sd[pre + k].double()
     lw, lb = g(f"{ax}_norm.gamma").reshape(-1), g(f"{ax}_norm.beta").reshape(-1)
-    gs = gate_prescale(64).to(lw.device)           # activation argument scale folded in (lh_common.h sigmoid_pre / tanh_pre)
     ws, bs = [], []
     for sfx in ("", "_reverse"):
         w = g(f"{ax}_rnn.weight_ih_l0{sfx}").reshape(256, 64, 4)                 # [col, c, k]
-        b = (g(f"{ax}_rnn.bias_ih_l0{sfx}") + g(f"{ax}_rnn.bias_hh_l0{sfx}") + (w * lb[None, :, None]).sum((1, 2))) * gs
-        w = (w * lw[None, :, None] * gs[:, None, None]).permute(0, 2, 1).reshape(256, 256)   # [col, k*64 + c]
+        b = g(f"{ax}_rnn.bias_ih_l0{sfx}") + g(f"{ax}_rnn.bias_hh_l0{sfx}") + (w * lb[None, :, None]).sum((1, 2))
+        w = (w * lw[None, :, None]).permute(0, 2, 1).reshape(256, 256)           # [col, k*64 + c]
         perm = (torch.arange(4, device=w.device)[None, :] * 64 + torch.arange(64, device=w.device)[:, None]).reshape(-1)  # new unit*4+gate <- gate*64+unit
         ws.append(w[perm]); bs.append(b[perm])
     out = {
         f"{ax}_wih": pack_linear_f16x3(torch.cat(ws, 0).float()), f"{ax}_bih": torch.cat(bs).float().contiguous(),
-        f"{ax}_whh": torch.stack([_pack_whh_f16x3((g(f"{ax}_rnn.weight_hh_l0") * gs[:, None]).float()),
-                                  _pack_whh_f16x3((g(f"{ax}_rnn.weight_hh_l0_reverse") * gs[:, None]).float())]),
+        f"{ax}_whh": torch.stack([_pack_whh_f16x3(sd[pre + f"{ax}_rnn.weight_hh_l0"]),
+                                  _pack_whh_f16x3(sd[pre + f"{ax}_rnn.weight_hh_l0_reverse"])]),
         f"{ax}_wct": pack_linear_f16x3(sd[pre + f"{ax}_linear.weight"].permute(1, 2, 0).reshape(64, 512).float().contiguous()),
         f"{ax}_bct": sd[pre + f"{ax}_linear.bias"].float().contiguous(),
     }

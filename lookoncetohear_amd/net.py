@@ -155,6 +155,7 @@ class Net(nn.Module):
         self._pack_key = None
         self._packed = None
         self._ws: Dict[tuple, dict] = {}
+        self._zeros: Dict[tuple, dict] = {}
         self._lib_override = None          # TEST HOOK ONLY (tests/hipemu): never set on the product path
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: list of (kernel tag, start event, end event) per launch
@@ -175,12 +176,14 @@ class Net(nn.Module):
         return dict(conv_buf=z(batch_size, self.num_ch * 2, 2, F_), deconv_buf=z(batch_size, C_, 2, F_),
                     istft_buf=z(batch_size, self.n_srcs, F_ * 2, 1), gridnet_bufs=bufs)
 
-    def predict(self, x, embed, input_state, pad=True):
+    def predict(self, x, embed, input_state, pad=True, want_state=True):
+        """Reference signature (net.py:54-66) plus `want_state`: False (only used by `forward` when it starts from the
+        zero state) skips materialising the next state, which `forward` discards anyway."""
         mod = 0
         if pad:
             pad_size = (0, self.stft_pad_size) if self.lookahead else (0, 0)
             x, mod = mod_pad(x, chunk_size=self.stft_chunk_size, pad=pad_size)
-        x, next_state = self._separate(x, embed, input_state)
+        x, next_state = self._separate(x, embed, input_state, want_state)
         # the kernels already leave out the stft_pad_size look-ahead tail the reference trims at net.py:61
         if mod != 0:
             x = x[:, :, :-mod]
@@ -188,9 +191,8 @@ class Net(nn.Module):
 
     def forward(self, x, embeds, input_state=None, pad=True):
         embeds = embeds[:, 0]  # [B, E]
-        if input_state is None:
-            input_state = self.init_buffers(x.shape[0], x.device)
-        x, next_state = self.predict(x, embeds, input_state, pad)
+        # zero initial state and the next state is dropped (reference net.py:68-76): no per-call state tensors
+        x, next_state = self.predict(x, embeds, input_state, pad, want_state=input_state is not None)
         return x
 
     def make_streamer(self, batch_size: int, device, use_graph: bool = True):
@@ -232,19 +234,29 @@ class Net(nn.Module):
             hist = self.local_atten_len - 1
             ws = dict(xa=e(B, T, F_, C_), xb=e(B, T, F_, C_), xc=e(B, T, F_, C_), hbuf=e(B * T * F_, 2 * self.hidden),
                       q=e(B * nh, T, 584), kx=torch.zeros(B * nh, T + hist, 584, device=device),
-                      vx=e(B * nh, T + hist, self.V_dim * F_), gain=e(B, F_, C_), gain_raw=e(B, F_ * C_))
+                      vx=e(B * nh, T + hist, self.V_dim * F_), gain=e(B, F_, C_), gain_raw=e(B, F_ * C_),
+                      hist_dirty=True)
             self._ws[key] = ws
         return ws
 
-    def _separate(self, x: torch.Tensor, embed: torch.Tensor, state: Optional[dict]):
+    def _zero_state(self, B, device) -> dict:
+        key = (B, str(device))
+        if key not in self._zeros:
+            if len(self._zeros) > 4:
+                self._zeros.clear()
+            self._zeros[key] = self.init_buffers(B, device)        # read-only: the kernels write state to separate tensors
+        return self._zeros[key]
+
+    def _separate(self, x: torch.Tensor, embed: torch.Tensor, state: Optional[dict], want_state: bool = True):
         """TFGridNet.forward (reference tfgridnet_causal.py:188-283) on the HIP kernels."""
         lib = self._lib(x)
         dev = x.device
         hop, nfft = self.stft_chunk_size, self.nfft
         assert x.dim() == 3 and x.shape[1] == self.num_ch, "input must be [B, num_ch, N]"
         Bn, _, n = x.shape
+        from_zero = state is None and not want_state
         if state is None:
-            state = self.init_buffers(Bn, dev)
+            state = self._zero_state(Bn, dev) if from_zero else self.init_buffers(Bn, dev)
         T = (n - nfft) // hop + 1
         if T < 1:
             raise ValueError(f"need at least {nfft} samples, got {n}")
@@ -318,8 +330,14 @@ class Net(nn.Module):
                     lib.call("lh_linear_res", P(hbuf), P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(xb), P(xc), rows,
                              H_, st)
                 # attention: history rows in, Q/K/V, local attention (head merge fused), projection + LN + residual
-                ws["kx"][:, :hist, :self.E * F_].copy_(bs["K_buf"])
-                ws["vx"][:, :hist].copy_(bs["V_buf"])
+                if not from_zero:
+                    ws["kx"][:, :hist, :self.E * F_].copy_(bs["K_buf"])
+                    ws["vx"][:, :hist].copy_(bs["V_buf"])
+                    ws["hist_dirty"] = True
+                elif ws["hist_dirty"]:                      # history rows of the window-extended buffers back to zero
+                    ws["kx"][:, :hist].zero_()
+                    ws["vx"][:, :hist].zero_()
+                    ws["hist_dirty"] = False
                 lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
                          P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
                          P(ws["kx"]), P(ws["vx"]), Bn, T, st)
@@ -328,9 +346,10 @@ class Net(nn.Module):
                 lib.call("lh_proj_ln_res", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
                          P(bp["proj_ln_w"]), P(bp["proj_ln_b"]), P(xc), P(gain) if gain is not None else None, P(xa),
                          Bn, T, st)
-                bs["h0"], bs["c0"] = hN, cN
-                bs["K_buf"] = ws["kx"][:, T:T + hist, :self.E * F_].contiguous()
-                bs["V_buf"] = ws["vx"][:, T:T + hist].contiguous()
+                if want_state:
+                    bs["h0"], bs["c0"] = hN, cN
+                    bs["K_buf"] = ws["kx"][:, T:T + hist, :self.E * F_].contiguous()
+                    bs["V_buf"] = ws["vx"][:, T:T + hist].contiguous()
                 if taps is not None:
                     taps[f"blocks.{i}.Y2"] = xc.clone()
                     taps[f"blocks.{i}.Q"] = ws["q"][:, :, :self.E * F_].clone()
@@ -343,8 +362,9 @@ class Net(nn.Module):
             y = torch.empty(Bn, self.n_srcs, hop * T, device=dev, dtype=torch.float32)
             lib.call("lh_deconv_istft", P(xa), P(dec_in), P(dec_out), P(ist_in), P(ist_out), P(pk["deconv_w"]),
                      P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), Bn, T, st)
-            state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
-        return y, state
+            if want_state:
+                state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
+        return y, (state if want_state else None)
 
 
 class Streamer:

@@ -49,13 +49,6 @@ def split_f16(v: torch.Tensor):
     return hi, lo
 
 
-def gate_prescale(hidden: int) -> torch.Tensor:
-    """[4*hidden] fp64 row scale of the (i, f, g, o) gate blocks: -log2(e) for the sigmoid gates, -2 log2(e) for g."""
-    import math
-    l2e = math.log2(math.e)
-    return torch.tensor([-l2e, -l2e, -2.0 * l2e, -l2e], dtype=torch.float64).repeat_interleave(hidden)
-
-
 def pack_lstm_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
     """Split-precision image for v_mfma_f32_16x16x32_f16: [4 waves, 4 gates, 4 ksteps, 64 lanes, 2 (hi|lo), 8] fp16.
 
@@ -102,21 +95,16 @@ def pack_block(sd: dict, pre: str) -> dict:
     # split-precision images with the LayerNorm affine folded in:  LN(x) W^T = xhat (W * ln_w)^T + W ln_b
     iw, ib = g("intra_norm.norm.weight").double(), g("intra_norm.norm.bias").double()
     ew, eb = g("inter_norm.norm.weight").double(), g("inter_norm.norm.bias").double()
-    # ... and the activation argument scale: sigmoid(v) = 1 / (1 + 2^(-log2(e) v)), tanh(v) = 2 / (1 + 2^(-2 log2(e) v)) - 1,
-    # so the rows of gates i, f, o are pre-multiplied by -log2(e) and those of g by -2 log2(e) (bias included) and the
-    # kernels feed the accumulators straight into v_exp_f32 (lh_common.h sigmoid_pre / tanh_pre)
-    gs = gate_prescale(g("intra_rnn.weight_hh_l0").shape[1]).to(iw.device)
-    fold_w = lambda w, lw: (w.double() * lw[None, :] * gs[:, None]).float()
-    fold_h = lambda w: (w.double() * gs[:, None]).float()
-    fold_b = lambda w, lb, b1, b2: ((b1.double() + b2.double() + w.double() @ lb) * gs).float()
+    fold_w = lambda w, lw: (w.double() * lw[None, :]).float()
+    fold_b = lambda w, lb, b1, b2: (b1.double() + b2.double() + w.double() @ lb).float()
     out["intra_w16"] = torch.stack([
-        pack_lstm_f16x3(fold_w(g("intra_rnn.weight_ih_l0"), iw), fold_h(g("intra_rnn.weight_hh_l0"))),
-        pack_lstm_f16x3(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw), fold_h(g("intra_rnn.weight_hh_l0_reverse")))])
+        pack_lstm_f16x3(fold_w(g("intra_rnn.weight_ih_l0"), iw), g("intra_rnn.weight_hh_l0")),
+        pack_lstm_f16x3(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw), g("intra_rnn.weight_hh_l0_reverse"))])
     out["intra_b16"] = torch.stack([
         fold_b(g("intra_rnn.weight_ih_l0"), ib, g("intra_rnn.bias_ih_l0"), g("intra_rnn.bias_hh_l0")),
         fold_b(g("intra_rnn.weight_ih_l0_reverse"), ib, g("intra_rnn.bias_ih_l0_reverse"),
                g("intra_rnn.bias_hh_l0_reverse"))])
-    out["inter_w16"] = pack_lstm_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew), fold_h(g("inter_rnn.weight_hh_l0"))).unsqueeze(0)
+    out["inter_w16"] = pack_lstm_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["inter_b16"] = fold_b(g("inter_rnn.weight_ih_l0"), eb, g("inter_rnn.bias_ih_l0"), g("inter_rnn.bias_hh_l0"))
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
