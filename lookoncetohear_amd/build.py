@@ -25,15 +25,17 @@ def _newer(dst, srcs):
     return all(os.path.getmtime(s) <= t for s in srcs)
 
 
-def build_hip(force: bool = False, verbose: bool = True) -> str:
+def build_hip(force: bool = False, verbose: bool = True, extra_flags=(), out: str = LIB) -> str:
+    """`extra_flags` / `out`: A/B variants of the same sources (e.g. -DLH_ACT_MERGED=1) built next to the product
+    library and selected with LOOKONCE_HIP_LIB (scripts/gpu_ab.sh); the product build uses the defaults."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "lh_common.h"),
                                                        os.path.join(os.path.dirname(PKG), "include", "lookonce_hip.h")]
-    if not force and _newer(LIB, deps):
-        return LIB
-    objdir = os.path.join(PKG, "build")
+    if not force and _newer(out, deps):
+        return out
+    objdir = os.path.join(PKG, "build" if out == LIB else "build_" + os.path.basename(out).replace(".so", ""))
     os.makedirs(objdir, exist_ok=True)
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", *extra_flags]
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -45,12 +47,18 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv))
+    # python -m lookoncetohear_amd.build [--force] [--variant NAME -DX=1 ...]  -> _lookonce_hip_NAME.so
+    if "--variant" in sys.argv:
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(build_hip(force=True, extra_flags=[a for a in sys.argv if a.startswith(("-D", "-f", "-m"))],
+                        out=os.path.join(PKG, f"_lookonce_hip_{name}.so")))
+    else:
+        print(build_hip(force="--force" in sys.argv))

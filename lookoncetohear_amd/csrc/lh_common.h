@@ -38,6 +38,15 @@ __device__ __forceinline__ float sigmoid_f(float x) {
 __device__ __forceinline__ float tanh_f(float x) {
     return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * LOG2E * x)) - 1.0f;
 }
+// One LSTM cell update (PyTorch gate order i,f,g,o): c' = sigma(f) c + sigma(i) tanh(g), h' = sigma(o) tanh(c').
+// (A variant over common denominators, 5 v_exp + 2 v_rcp instead of 5 + 5, measured the same on the MI355X:
+//  profiles/r01i_lab_lstm_attn_variants.txt — the recurrence is not bound by transcendental issue.)
+__device__ __forceinline__ void lstm_cell(float gi, float gf, float gg, float go, float& c, float& h) {
+    const float ig = sigmoid_f(gi), fg = sigmoid_f(gf), g2 = tanh_f(gg), og = sigmoid_f(go);
+    const float cc = fg * c + ig * g2;
+    c = cc;
+    h = og * tanh_f(cc);
+}
 __device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
 
 // sum over the 64 lanes of a wave (every lane gets the total): 4 DPP row steps + 2 cross-row shuffles

@@ -461,13 +461,9 @@ __global__ void __launch_bounds__(256, 2) k_emb_lstm(const float* __restrict__ g
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float ig = sigmoid_f(am[0][r] + ac[0][r] * INV);
-            const float fg = sigmoid_f(am[1][r] + ac[1][r] * INV);
-            const float gg = tanh_f(am[2][r] + ac[2][r] * INV);
-            const float og = sigmoid_f(am[3][r] + ac[3][r] * INV);
-            const float cc = fg * creg[r] + ig * gg;
-            creg[r] = cc;
-            const float hv = og * tanh_f(cc);
+            float hv;
+            lstm_cell(am[0][r] + ac[0][r] * INV, am[1][r] + ac[1][r] * INV, am[2][r] + ac[2][r] * INV,
+                      am[3][r] + ac[3][r] * INV, creg[r], hv);
             const int row = g4 * 4 + r;
             const _Float16 th = (_Float16)hv;
             ahi[(nxt * 16 + row) * EL_AP + unit] = th;

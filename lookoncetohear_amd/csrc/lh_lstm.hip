@@ -358,13 +358,8 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float ig = sigmoid_f(gate[m][0][r]);
-                const float fg = sigmoid_f(gate[m][1][r]);
-                const float gg = tanh_f(gate[m][2][r]);
-                const float og = sigmoid_f(gate[m][3][r]);
-                const float cc = fg * creg[m][r] + ig * gg;
-                creg[m][r] = cc;
-                const float hv = og * tanh_f(cc);
+                float hv;
+                lstm_cell(gate[m][0][r], gate[m][1][r], gate[m][2][r], gate[m][3][r], creg[m][r], hv);
                 const int rl = m * 16 + g4 * 4 + r;
                 _Float16 th, tl;
                 split_f16(hv, th, tl);
@@ -601,13 +596,8 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float ig = sigmoid_f(gate[m][0][r]);
-                    const float fg = sigmoid_f(gate[m][1][r]);
-                    const float gg = tanh_f(gate[m][2][r]);
-                    const float og = sigmoid_f(gate[m][3][r]);
-                    const float cc = fg * creg[m][r] + ig * gg;
-                    creg[m][r] = cc;
-                    const float hv = og * tanh_f(cc);
+                    float hv;
+                    lstm_cell(gate[m][0][r], gate[m][1][r], gate[m][2][r], gate[m][3][r], creg[m][r], hv);
                     const int rl = m * 16 + g4 * 4 + r;
                     _Float16 th, tl;
                     split_f16(hv, th, tl);

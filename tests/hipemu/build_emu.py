@@ -10,20 +10,20 @@ OUT = os.path.join(HERE, "_build", "liblookonce_emu.so")
 SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip"]
 
 
-def build_emu(force=False):
+def build_emu(force=False, extra_flags=(), out=OUT):
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = "clang++"
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "lh_common.h"),
                                                        os.path.join(HERE, "include", "hip", "hip_runtime.h"),
                                                        os.path.join(ROOT, "include", "lookonce_hip.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-march=native",
-           "-I", os.path.join(HERE, "include"), *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-march=native", *extra_flags,
+           "-I", os.path.join(HERE, "include"), *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
