@@ -45,7 +45,8 @@ int lh_abi_version(void);
 
 /* Launch-shape tuning knobs (benchmark A/B only; 0 = automatic): key 0 = sequences-per-workgroup/16 of the
  * intra LSTM, key 1 = same for the inter LSTM, key 3 = 0 switches off the issue-priority de-phasing of the two
- * workgroups that share a CU in the fused recurrent kernels (default on). */
+ * workgroups that share a CU in the fused recurrent kernels (default on), key 4 = query tiles of 16 frames per
+ * attention workgroup (1 or 2, default 2). */
 int lh_set_tuning(int key, int value);
 
 /* Validates model_params (reference net.py:21-49 / configs/tsh.json:5-19) against the compiled constants. */
@@ -118,29 +119,44 @@ int lh_inter_block(const float* x, const void* w_pk, const float* b_sum, const v
 int lh_linear_res(const float* h, const void* w_pk, const float* bias, const float* res, float* out, int rows,
                   int K, lh_stream_t stream);
 
+/* Split-precision activation rows shared by lh_qkv_proj_ln / lh_local_attn / lh_ring_pack / lh_ring_unpack.
+ * Every value v is stored as two fp16 numbers  hi = fp16(v), lo = fp16((v - hi) * 2^11)  (4 bytes per element,
+ * like fp32; v ~ hi + 2^-11 lo keeps ~22 mantissa bits) in the order the attention MFMA operands consume:
+ *   q   [B*4][T][1216 halves]          per row 76 blocks of 8 features (f*6+e), each [hi 8 | lo 8]; features
+ *                                      582..607 are zero
+ *   kx  [B*4][T+49+PAD][1216 halves]   same row format; rows 0..48 = history (K_buf), row 49+t = K[t]
+ *   vx  [B*4][T+49+PAD][3104 halves]   per row 388 quads of 4 columns (f*16+v), each [hi 4 | lo 4]
+ * PAD = LH_KV_PAD_ROWS rows behind row T+48 that the CALLER zero-fills once and the library never writes: attention
+ * tiles read (without needing them) up to 47 rows past their last key. */
+#define LH_KV_PAD_ROWS 48
+
 /* A.3.3  Q/K/V: pointwise Linear + PReLU, head split, joint LayerNorm over (f,e) per head.
  * Replaces attn_conv_Q/K/V (tfgridnet_causal.py:354-387, used :547-551) and the K/V history concat (:553-562):
- * K and V rows are written at row (hist + t) of the history-extended buffers.
+ * K and V rows are written at row (49 + t) of the history-extended buffers.
  *   y      [B][T][97][64]
  *   w_pk   fp16 hi/lo image [7 ntiles][2 ksteps][64 lanes][16] of the stacked weight, rows 0..23 Q(h*6+e),
  *          24..47 K, 48..111 V(h*16+v); bias [112]
- *   slopes [3] PReLU slopes (Q,K,V);  lnq_w/b, lnk_w/b [582];  lnv_w/b [1552]
- *   q      [B*4][T][584]            (row stride 584 = 582 padded to 16 B; pad columns are written as 0)
- *   kx     [B*4][T+49][584]         rows 0..48 = history (filled by the caller from K_buf), row 49+t = K[t]
- *   vx     [B*4][T+49][1552]
+ *   slopes [3] PReLU slopes (Q,K,V);  lnq_w/b, lnk_w/b [608] = the 582 affine values zero-padded;  lnv_w/b [1552]
+ *   q, kx, vx  split-precision rows (above)
  */
 int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const float* slopes, const float* lnq_w,
                    const float* lnq_b, const float* lnk_w, const float* lnk_b, const float* lnv_w,
-                   const float* lnv_b, float* q, float* kx, float* vx, int B, int T, lh_stream_t stream);
+                   const float* lnv_b, void* q, void* kx, void* vx, int B, int T, lh_stream_t stream);
 
 /* A.3.5  local windowed attention over exactly 50 slots (frames t-49..t incl. history rows, no mask) with
  * the head merge fused into the store.  Replaces tfgridnet_causal.py:564-581 without materialising the
  * 50x unfolded K/V (`_causal_unfold_chunk`, :429-454).
- *   q [B*4][T][584]; kx [B*4][T+49][584]; vx [B*4][T+49][1552]
+ *   q, kx, vx  split-precision rows (above)
  *   merged [B][T][4][97][16]   merged[b][t][h][f][v] = O[b*4+h][t][f*16+v]   (head-major frame slabs)
  */
-int lh_local_attn(const float* q, const float* kx, const float* vx, float* merged, int B, int T,
-                  lh_stream_t stream);
+int lh_local_attn(const void* q, const void* kx, const void* vx, float* merged, int B, int T, lh_stream_t stream);
+
+/* A.3.4  streaming state <-> history rows (tfgridnet_causal.py:553-562).  The reference carries the last 49 K / V
+ * rows as fp32 state:  lh_ring_pack writes k_buf [B*4][49][582] / v_buf [B*4][49][1552] into rows 0..48 of kx / vx
+ * before lh_qkv_proj_ln;  lh_ring_unpack reads rows T..T+48 (the new history) back into fp32 state tensors
+ * (hi + 2^-11 lo, i.e. exactly the values the attention kernel used). */
+int lh_ring_pack(const float* k_buf, const float* v_buf, void* kx, void* vx, int B, int T, lh_stream_t stream);
+int lh_ring_unpack(const void* kx, const void* vx, float* k_buf, float* v_buf, int B, int T, lh_stream_t stream);
 
 /* A.3.6  attn_concat_proj: Linear(64->64)+PReLU, joint LayerNorm over (f,c), residual; optional speaker gain.
  * Replaces tfgridnet_causal.py:583-588 and, when gain != NULL, the `batch = batch * embed` applied to the

@@ -1,191 +1,370 @@
 // Local (50-slot) causal attention with fused head merge, SURVEY.md §8a rows a15-a18.
 //
 // The reference materialises a 50x sliding-window copy of K and V (`_causal_unfold_chunk`,
-// tfgridnet_causal.py:429-454: 67 % of its CPU time).  Here a workgroup owns 16 consecutive query frames of
-// one (batch, head): the 65 history-extended K/V rows they can see are read ONCE from the ring-extended
-// buffers, scores are a banded 16 x 80 fp32-MFMA product split over the feature axis across the 4 waves,
-// softmax runs over exactly the 50 in-window slots (zero history rows take part, no mask — reference
-// behaviour), and P.V streams V rows as 256-byte float4 row segments straight into MFMA B operands.  The output
-// keeps the head-major order [B][T][head][97][16] (full-line stores; interleaving the heads at 64-byte granularity
-// made every cache line a partial write of two workgroups) — the projection kernel reads it in that order.
-// Workgroups of one (batch, head) are placed on one XCD (blockIdx % 8) so neighbouring tiles re-read the
-// shared 49 rows from that XCD's L2 instead of HBM.
+// tfgridnet_causal.py:429-454: 67 % of its CPU time).  Here a workgroup owns TQ = 16*MQ consecutive query frames of
+// one (batch, head): the TQ+49 history-extended K/V rows they can see are read ONCE from the ring-extended buffers.
+//
+// Q, K and V arrive as split-precision fp16 pairs (v = hi + 2^-11 lo, written by k_qkv_proj_ln in exactly the order
+// the v_mfma_f32_16x16x32_f16 operands want, lh_common.h), so both contractions run as three fp16 MFMAs per tile
+// (hi*hi + 2^-11 (hi*lo + lo*hi), ~22 mantissa bits) with no conversion work in this kernel:
+//   * scores  S = Q K^T: banded tile products (query tile mq x key tiles mq..mq+4), the 19 feature k-steps split
+//     over the 4 waves, partial sums reduced through LDS; A and B fragments are 32-byte row segments straight from
+//     global memory (two-deep register ring);
+//   * softmax over exactly the 50 in-window slots (zero history rows take part, no mask — reference behaviour),
+//     P written to LDS as fp16 hi/lo rows;
+//   * O = P V: per 32-key step a lane loads the [hi 4 | lo 4] quads of 8 key rows for its 4 columns (256-byte row
+//     segments per 16 lanes) and regroups them lane-locally into the four column tiles' B operands; the three key
+//     steps form a register ring that is refilled for the wave's next column group right after use.
+// The output keeps the head-major order [B][T][head][97][16] (full-line stores) — the projection kernel reads it in
+// that order.  Workgroups of one (batch, head) are placed on one XCD (blockIdx % 8) so neighbouring tiles re-read
+// the shared 49 rows from that XCD's L2 instead of HBM.  kx / vx carry KV_PAD zero rows behind row T+48: tiles
+// read (never need) up to 47 rows past their last key and 0 * finite = 0.
 #include "lh_common.h"
 
 namespace lh {
 
-constexpr int AT_TQ = 16;                  // query frames per workgroup
-constexpr int AT_NKT = 5;                  // key tiles of 16 -> 80 >= 16 + 49 rows
-constexpr int AT_NK = AT_NKT * 16;         // 80
-constexpr int AT_KS = 17;                  // k-steps of 4 keys in P.V (68 >= 65)
-constexpr int AT_PP = AT_KS * 4 + 4;       // P row stride (72)
-constexpr int AT_F4 = LDQK / 4;            // 146 float4 per q/k row
-constexpr int AT_CG = (DV + 63) / 64;      // 25 column groups of 64 V columns
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+struct Frag { f16x8 h, l; };               // 8 k-values of one operand row: hi and lo halves
+struct VQuad { f16x4 h, l; };              // one key row, 4 columns
 
-__global__ void __launch_bounds__(256) k_local_attn(const float* __restrict__ q, const float* __restrict__ kx,
-                                                    const float* __restrict__ vx, float* __restrict__ merged,
-                                                    int BH, int T, int ntt) {
-    __shared__ float sp[4][AT_TQ][AT_NK];
-    __shared__ float pm[AT_TQ][AT_PP];
+constexpr int AT_KSTEPS = (DQKP + 31) / 32;   // 19 feature k-steps of 32
+constexpr int AT_PKS = 3;                     // 32-key steps in P.V (96 >= 32 + 49)
+constexpr int AT_PP = AT_PKS * 32 + 8;        // P row stride in halves (208 bytes: conflict-free ds_read_b128)
+constexpr int AT_CG = (DV + 63) / 64;         // 25 column groups of 64 V columns
+
+template <int MQ, int RING>
+__global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restrict__ q, const _Float16* __restrict__ kx,
+                                                       const _Float16* __restrict__ vx, float* __restrict__ merged,
+                                                       int BH, int T, int ntt) {
+    constexpr int TQ = 16 * MQ;                // query frames per workgroup
+    constexpr int NKEYS = TQ + HIST;           // key rows they can see (65 / 81)
+    constexpr int NKT = (NKEYS + 15) / 16;     // key tiles in the score phase (5 / 6)
+    constexpr int NK = NKT * 16;
+    constexpr int ND = 5;                      // key tiles per query tile: nt = mq .. mq+4
+    static_assert(NKEYS <= AT_PKS * 32 && NKT == MQ + ND - 1 && NK - 1 <= HIST + KV_PAD, "tile geometry");
+    __shared__ float sp[4][TQ][NK];
+    __shared__ __attribute__((aligned(16))) _Float16 ph[TQ][AT_PP];
+    __shared__ __attribute__((aligned(16))) _Float16 pl[TQ][AT_PP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
     // XCD-aware placement: the tiles of (batch, head) bh all run on XCD bh % 8
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
     const int bh = (kk / ntt) * 8 + xcd;
-    const int t0 = (kk % ntt) * AT_TQ;
+    const int t0 = (kk % ntt) * TQ;
     if (bh >= BH) return;
-    const int TK = T + HIST;
-    const float* qb = q + (long)bh * T * LDQK;
-    const float* kb = kx + (long)bh * TK * LDQK;
-    const float* vb = vx + (long)bh * TK * DV;
+    const long TKP = T + HIST + KV_PAD;
+    const _Float16* qb = q + (long)bh * T * LDQKH;
+    const _Float16* kb = kx + ((long)bh * TKP + t0) * LDQKH;
+    const _Float16* vb = vx + ((long)bh * TKP + t0) * LDVH;
+    constexpr float INV = 1.0f / SPLIT_F;
 
-    // ---- scores: S[i][n] = <Q[t0+i], Kx[t0+n]>, feature axis split over waves and 16-lane groups
+    // ---- scores: S[i][n] = <Q[t0+i], Kx[t0+n]>, feature k-steps s = wave, wave+4, ... of 19
     {
-        f32x4 acc[AT_NKT];
+        f32x4 am[MQ][ND], ac[MQ][ND];
 #pragma unroll
-        for (int nt = 0; nt < AT_NKT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* qrow = qb + (long)min(t0 + l15, T - 1) * LDQK;
-        const float* krow[AT_NKT];
+        for (int mq = 0; mq < MQ; ++mq)
 #pragma unroll
-        for (int nt = 0; nt < AT_NKT; ++nt) krow[nt] = kb + (long)min(t0 + nt * 16 + l15, TK - 1) * LDQK;
-        // two-deep register ring over the feature iterations: the 6 row segments of iteration it+1 are in flight
-        // while the 20 MFMAs of iteration it run (the compiler otherwise waits for every load right before its use)
-        constexpr int NIT = (AT_F4 + 15) / 16;
-        float4 ring[2][AT_NKT + 1];
-        auto fetch = [&](int it, float4 (&dst)[AT_NKT + 1]) {
-            const int f4 = it * 16 + wave * 4 + g4;
-            const int off = f4 < AT_F4 ? f4 * 4 : 0;
-            dst[AT_NKT] = *reinterpret_cast<const float4*>(qrow + off);
+            for (int d = 0; d < ND; ++d) {
+                am[mq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ac[mq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        int qoff[MQ], koff[NKT];
 #pragma unroll
-            for (int nt = 0; nt < AT_NKT; ++nt) dst[nt] = *reinterpret_cast<const float4*>(krow[nt] + off);
-        };
-        auto mma = [&](int it, const float4 (&src)[AT_NKT + 1]) {
-            const bool ok = it * 16 + wave * 4 + g4 < AT_F4;
-            const float4 a4 = src[AT_NKT];
-            const float av[4] = {ok ? a4.x : 0.f, ok ? a4.y : 0.f, ok ? a4.z : 0.f, ok ? a4.w : 0.f};
+        for (int mq = 0; mq < MQ; ++mq) qoff[mq] = min(t0 + mq * 16 + l15, T - 1) * LDQKH + g4 * 16;
 #pragma unroll
-            for (int nt = 0; nt < AT_NKT; ++nt) {
-                const float bv[4] = {src[nt].x, src[nt].y, src[nt].z, src[nt].w};
+        for (int nt = 0; nt < NKT; ++nt) koff[nt] = (nt * 16 + l15) * LDQKH + g4 * 16;
+        constexpr int NIT = (AT_KSTEPS + 3) / 4;       // 5 (wave 3 runs 4)
+        Frag fq[2][MQ], fk[2][NKT];
+        auto fetch = [&](int it, Frag (&dq)[MQ], Frag (&dk)[NKT]) {
+            const int s = min(wave + 4 * it, AT_KSTEPS - 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[nt], 0, 0, 0);
+            for (int mq = 0; mq < MQ; ++mq) {
+                const _Float16* p = qb + qoff[mq] + s * 64;
+                dq[mq].h = *reinterpret_cast<const f16x8*>(p);
+                dq[mq].l = *reinterpret_cast<const f16x8*>(p + 8);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NKT; ++nt) {
+                const _Float16* p = kb + koff[nt] + s * 64;
+                dk[nt].h = *reinterpret_cast<const f16x8*>(p);
+                dk[nt].l = *reinterpret_cast<const f16x8*>(p + 8);
             }
         };
-        static_assert(NIT % 2 == 0, "ring parity");
-        fetch(0, ring[0]);
-#pragma unroll 1
-        for (int it = 0; it < NIT; it += 2) {
-            fetch(it + 1, ring[1]);
-            mma(it, ring[0]);
-            fetch(min(it + 2, NIT - 1), ring[0]);
-            mma(it + 1, ring[1]);
+        auto mma = [&](const Frag (&sq)[MQ], const Frag (&sk)[NKT]) {
+#pragma unroll
+            for (int mq = 0; mq < MQ; ++mq)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const Frag& kf = sk[mq + d];
+                    am[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].h, kf.h, am[mq][d], 0, 0, 0);
+                    ac[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].h, kf.l, ac[mq][d], 0, 0, 0);
+                    ac[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].l, kf.h, ac[mq][d], 0, 0, 0);
+                }
+        };
+        fetch(0, fq[0], fk[0]);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it + 1 < NIT) fetch(it + 1, fq[(it + 1) & 1], fk[(it + 1) & 1]);
+            if (wave + 4 * it < AT_KSTEPS) mma(fq[it & 1], fk[it & 1]);       // wave-uniform
         }
 #pragma unroll
-        for (int nt = 0; nt < AT_NKT; ++nt)
+        for (int mq = 0; mq < MQ; ++mq)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sp[wave][g4 * 4 + r][nt * 16 + l15] = acc[nt][r];
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sp[wave][mq * 16 + g4 * 4 + r][(mq + d) * 16 + l15] = am[mq][d][r] + ac[mq][d][r] * INV;
     }
     __syncthreads();
 
-    // ---- softmax over the 50 slots n = i .. i+49 of query i; 16 threads per query
+    // ---- softmax over the 50 slots n = i .. i+49 of query i; 16 threads per query, P as fp16 hi/lo rows
     {
-        const int i = tid >> 4, sub = tid & 15;
         const float scale = 1.0f / sqrtf((float)DQK);
-        float sv[4];
-        float mx = -3.0e38f;
+        constexpr int NU = AT_PKS * 2;            // 6 column slots of 16 per thread (96 key columns)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = sub + 16 * u;
-            float s = -3.0e38f;
-            if (j < WIN) {
-                const int n = i + j;
-                s = (sp[0][i][n] + sp[1][i][n] + sp[2][i][n] + sp[3][i][n]) * scale;
+        for (int pass = 0; pass < MQ; ++pass) {
+            const int i = pass * 16 + (tid >> 4), sub = tid & 15;
+            float sv[NU];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int n = sub + 16 * u, j = n - i;
+                float s = -3.0e38f;
+                if (j >= 0 && j < WIN) s = (sp[0][i][n] + sp[1][i][n] + sp[2][i][n] + sp[3][i][n]) * scale;
+                sv[u] = s;
+                mx = fmaxf(mx, s);
             }
-            sv[u] = s;
-            mx = fmaxf(mx, s);
-        }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f;
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sum = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = sub + 16 * u;
-            sv[u] = (j < WIN) ? __expf(sv[u] - mx) : 0.f;
-            sum += sv[u];
-        }
-        sum = group16_sum(sum);
-        const float inv = 1.0f / sum;
-        for (int n = sub; n < AT_PP; n += 16) pm[i][n] = 0.f;      // outside the band
-        __syncthreads();
+            for (int u = 0; u < NU; ++u) {
+                const int j = sub + 16 * u - i;
+                sv[u] = (j >= 0 && j < WIN) ? __expf(sv[u] - mx) : 0.f;
+                sum += sv[u];
+            }
+            sum = group16_sum(sum);
+            const float inv = 1.0f / sum;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = sub + 16 * u;
-            if (j < WIN) pm[i][i + j] = sv[u] * inv;
+            for (int u = 0; u < NU; ++u) {
+                const float p = sv[u] * inv;           // exactly 0 outside the band
+                const _Float16 h = (_Float16)p;
+                ph[i][sub + 16 * u] = h;
+                pl[i][sub + 16 * u] = (_Float16)((p - (float)h) * SPLIT_F);
+            }
         }
     }
     __syncthreads();
 
-    // ---- O = P . Vx ; each wave takes column groups of 64 (4 MFMA column tiles interleaved so a lane loads
-    //      one float4 of a V row per k-step); the head merge is fused into the store
+    // ---- O = P . Vx ; each wave takes column groups of 64 (4 MFMA column tiles interleaved so a lane loads one
+    //      [hi 4 | lo 4] quad of a V row per key); the head merge is fused into the store
     {
-        float pa[AT_KS];
-#pragma unroll
-        for (int ks = 0; ks < AT_KS; ++ks) pa[ks] = pm[l15][ks * 4 + g4];
         const int b = bh / NH, hd = bh % NH;
-        // V-row ring: slot ks is refilled with the next column group's row segment right after its 4 MFMAs, so
-        // every load has the other 16 k-steps (64 MFMAs) to land
-        int vrow[AT_KS];
+        // key row of (step ks, slot j) for this lane: 32 ks + 8 g4 + j; rows >= NKEYS are never needed (P = 0 there)
+        const int lrow = g4 * 8 * LDVH;
+        auto qcol = [&](int cg) { return min(min(cg, AT_CG - 1) * 16 + l15, DV / 4 - 1) * 8; };   // quad offset in halves
+        // Register ring over the flattened (column group, key step) sequence of this wave: step s uses slot s % RING
+        // and, before its MFMAs, refills the slot of step s-1 with the rows of step s+RING-1.
+        VQuad ring[RING][8];
+        auto fill = [&](int slot, int ks, int qc) {
 #pragma unroll
-        for (int ks = 0; ks < AT_KS; ++ks) vrow[ks] = min(t0 + ks * 4 + g4, TK - 1);
-        auto vcol = [&](int cg) { const int c = min(cg, AT_CG - 1) * 64 + l15 * 4; return c < DV ? c : 0; };
-        float4 vr[AT_KS];
-        {
-            const int lc = vcol(wave);
+            for (int j = 0; j < 8; ++j) {
+                VQuad v;
+                v.h = f16x4{0, 0, 0, 0};
+                v.l = f16x4{0, 0, 0, 0};
+                if (32 * ks + 8 * g4 + j < NKEYS) {
+                    const _Float16* p = vb + lrow + (32 * ks + j) * LDVH + qc;
+                    v.h = *reinterpret_cast<const f16x4*>(p);
+                    v.l = *reinterpret_cast<const f16x4*>(p + 4);
+                }
+                ring[slot][j] = v;
+            }
+        };
 #pragma unroll
-            for (int ks = 0; ks < AT_KS; ++ks) vr[ks] = *reinterpret_cast<const float4*>(vb + (long)vrow[ks] * DV + lc);
-        }
+        for (int s = 0; s < RING - 1; ++s) fill(s % RING, s % AT_PKS, qcol(wave + 4 * (s / AT_PKS)));
+        f32x4 am[MQ][4], ac[MQ][4];
         // fully unrolled (7 column groups for wave 0, 6 for the others): exact vmcnt waits instead of a drain of the
         // ring at every loop back-edge
+        constexpr int NSTEP = ((AT_CG + 3) / 4) * AT_PKS;
 #pragma unroll
-        for (int ci = 0; ci < (AT_CG + 3) / 4; ++ci) {
-            const int cg = wave + 4 * ci;
+        for (int s = 0; s < NSTEP; ++s) {
+            const int ks = s % AT_PKS, cg = wave + 4 * (s / AT_PKS);
             if (cg >= AT_CG) break;                    // wave-uniform
-            const int col = cg * 64 + l15 * 4;
-            const bool colok = col < DV;
-            const int ncol = vcol(cg + 4);
-            f32x4 acc[4];
+            if (ks == 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int mq = 0; mq < MQ; ++mq)
 #pragma unroll
-            for (int ks = 0; ks < AT_KS; ++ks) {
-                const float4 v4 = vr[ks];
-                vr[ks] = *reinterpret_cast<const float4*>(vb + (long)vrow[ks] * DV + ncol);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ks], v4.w, acc[3], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);      // keep the refill next to its slot's MFMAs (the scheduler sinks it)
+                    for (int c = 0; c < 4; ++c) {
+                        am[mq][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        ac[mq][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
             }
-            if (colok) {
+            {
+                const int sn = s + RING - 1, cgn = wave + 4 * (sn / AT_PKS);
+                if (cgn < AT_CG) fill(sn % RING, sn % AT_PKS, qcol(cgn));
+            }
+            // regroup: column tile c takes element c of the 8 key rows -> one f16x8 B operand (hi and lo)
+            f16x8 bh8[4], bl8[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = t0 + g4 * 4 + r;
-                    if (t < T)      // head-major slab [b][t][hd][f][v]: one head's frame is 6208 contiguous bytes
-                        *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * NH + hd) * DV + col]) =
-                            make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bh8[c][j] = ring[s % RING][j].h[c];
+                    bl8[c][j] = ring[s % RING][j].l[c];
                 }
+#pragma unroll
+            for (int mq = 0; mq < MQ; ++mq) {
+                const f16x8 pa = *reinterpret_cast<const f16x8*>(&ph[mq * 16 + l15][ks * 32 + g4 * 8]);
+                const f16x8 pb = *reinterpret_cast<const f16x8*>(&pl[mq * 16 + l15][ks * 32 + g4 * 8]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    am[mq][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bh8[c], am[mq][c], 0, 0, 0);
+                    ac[mq][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bl8[c], ac[mq][c], 0, 0, 0);
+                    ac[mq][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, bh8[c], ac[mq][c], 0, 0, 0);
+                }
+            }
+            const int col = cg * 64 + l15 * 4;
+            if (ks == AT_PKS - 1 && col < DV) {
+#pragma unroll
+                for (int mq = 0; mq < MQ; ++mq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int t = t0 + mq * 16 + g4 * 4 + r;
+                        if (t < T)      // head-major slab [b][t][hd][f][v]: one head's frame is 6208 contiguous bytes
+                            *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * NH + hd) * DV + col]) =
+                                make_float4(am[mq][0][r] + ac[mq][0][r] * INV, am[mq][1][r] + ac[mq][1][r] * INV,
+                                            am[mq][2][r] + ac[mq][2][r] * INV, am[mq][3][r] + ac[mq][3][r] * INV);
+                    }
             }
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Streaming state <-> ring rows: the reference carries K_buf [4B][49][582] / V_buf [4B][49][1552] as fp32
+// (tfgridnet_causal.py:553-562); the history rows of kx / vx hold the same numbers as split fp16 pairs.
+//   pack:   rows 0..48 of kx / vx   <- K_buf / V_buf
+//   unpack: K_buf / V_buf           <- rows T..T+48 of kx / vx  (hi + 2^-11 lo: the value the attention kernel used)
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ring_pack(const float* __restrict__ kbuf, const float* __restrict__ vbuf,
+                                                   _Float16* __restrict__ kx, _Float16* __restrict__ vx, long tkp, int BH) {
+    const long nk = (long)BH * HIST * QKB, nv = (long)BH * HIST * (DV / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nk + nv; i += (long)gridDim.x * 256) {
+        if (i < nk) {                                   // one 8-feature block of a K row
+            const long row = i / QKB;
+            const int blk = (int)(i % QKB);
+            const long bh = row / HIST, r = row % HIST;
+            f16x8 h8, l8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int f = blk * 8 + e;
+                const float v = f < DQK ? kbuf[row * DQK + f] : 0.f;
+                const _Float16 h = (_Float16)v;
+                h8[e] = h;
+                l8[e] = (_Float16)((v - (float)h) * SPLIT_F);
+            }
+            _Float16* d = kx + (bh * tkp + r) * LDQKH + blk * 16;
+            *reinterpret_cast<f16x8*>(d) = h8;
+            *reinterpret_cast<f16x8*>(d + 8) = l8;
+        } else {                                        // one 4-column quad of a V row
+            const long k = i - nk;
+            const long row = k / (DV / 4);
+            const int qd = (int)(k % (DV / 4));
+            const long bh = row / HIST, r = row % HIST;
+            const float4 v4 = *reinterpret_cast<const float4*>(&vbuf[row * DV + qd * 4]);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 h = (_Float16)v[e];
+                o[e] = h;
+                o[4 + e] = (_Float16)((v[e] - (float)h) * SPLIT_F);
+            }
+            *reinterpret_cast<f16x8*>(vx + (bh * tkp + r) * LDVH + qd * 8) = o;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ring_unpack(const _Float16* __restrict__ kx, const _Float16* __restrict__ vx,
+                                                     float* __restrict__ kbuf, float* __restrict__ vbuf, long tkp, int T,
+                                                     int BH) {
+    const long nk = (long)BH * HIST * QKB, nv = (long)BH * HIST * (DV / 4);
+    constexpr float INV = 1.0f / SPLIT_F;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nk + nv; i += (long)gridDim.x * 256) {
+        if (i < nk) {
+            const long row = i / QKB;
+            const int blk = (int)(i % QKB);
+            const long bh = row / HIST, r = row % HIST;
+            const _Float16* s = kx + (bh * tkp + T + r) * LDQKH + blk * 16;
+            const f16x8 h8 = *reinterpret_cast<const f16x8*>(s), l8 = *reinterpret_cast<const f16x8*>(s + 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int f = blk * 8 + e;
+                if (f < DQK) kbuf[row * DQK + f] = (float)h8[e] + (float)l8[e] * INV;
+            }
+        } else {
+            const long k = i - nk;
+            const long row = k / (DV / 4);
+            const int qd = (int)(k % (DV / 4));
+            const long bh = row / HIST, r = row % HIST;
+            const f16x8 o = *reinterpret_cast<const f16x8*>(vx + (bh * tkp + T + r) * LDVH + qd * 8);
+            *reinterpret_cast<float4*>(&vbuf[row * DV + qd * 4]) =
+                make_float4((float)o[0] + (float)o[4] * INV, (float)o[1] + (float)o[5] * INV,
+                            (float)o[2] + (float)o[6] * INV, (float)o[3] + (float)o[7] * INV);
+        }
+    }
+}
+
+static int g_attn_mq = 2;              // query tiles of 16 frames per workgroup (lh_set_tuning key 4: 1 or 2)
+int attn_set_mq(int v) {
+    if (v != 1 && v != 2) return LH_ERR_ARG;
+    g_attn_mq = v;
+    return LH_OK;
+}
+
 }  // namespace lh
 
-extern "C" int lh_local_attn(const float* q, const float* kx, const float* vx, float* merged, int B, int T,
+extern "C" int lh_local_attn(const void* q, const void* kx, const void* vx, float* merged, int B, int T,
                              lh_stream_t stream) {
     using namespace lh;
     if (!q || !kx || !vx || !merged || B <= 0 || T <= 0) return LH_ERR_ARG;
     const int BH = B * NH;
-    const int ntt = (T + AT_TQ - 1) / AT_TQ;
     const int bh8 = (BH + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_local_attn, dim3(bh8 * ntt), dim3(256), 0, (hipStream_t)stream, q, kx, vx, merged, BH, T, ntt);
+    // a single query tile when the clip is that short (streaming: T = 1) — the second tile would be all padding
+    // two query tiles per workgroup share every K / V row they load (25 instead of 44 KB of L2 traffic per query;
+    // measured 0.36 against 0.43 ms at B = 32); a single tile when the clip is that short (streaming: T = 1).
+    // The two-tile kernel runs a two-deep V ring: with three slots it needs more than 256 registers.
+    const int mq = T <= 16 ? 1 : g_attn_mq;
+    const int ntt = (T + 16 * mq - 1) / (16 * mq);
+    const dim3 grid(bh8 * ntt);
+    const _Float16 *qh = (const _Float16*)q, *kh = (const _Float16*)kx, *vh = (const _Float16*)vx;
+    if (mq == 1)
+        hipLaunchKernelGGL((k_local_attn<1, 3>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
+    else
+        hipLaunchKernelGGL((k_local_attn<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
+    return check_launch();
+}
+
+extern "C" int lh_ring_pack(const float* k_buf, const float* v_buf, void* kx, void* vx, int B, int T,
+                            lh_stream_t stream) {
+    using namespace lh;
+    if (!k_buf || !v_buf || !kx || !vx || B <= 0 || T <= 0) return LH_ERR_ARG;
+    const int BH = B * NH;
+    const long n = (long)BH * HIST * (QKB + DV / 4);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_ring_pack, dim3(grid), dim3(256), 0, (hipStream_t)stream, k_buf, v_buf, (_Float16*)kx,
+                       (_Float16*)vx, (long)T + HIST + KV_PAD, BH);
+    return check_launch();
+}
+
+extern "C" int lh_ring_unpack(const void* kx, const void* vx, float* k_buf, float* v_buf, int B, int T,
+                              lh_stream_t stream) {
+    using namespace lh;
+    if (!k_buf || !v_buf || !kx || !vx || B <= 0 || T <= 0) return LH_ERR_ARG;
+    const int BH = B * NH;
+    const long n = (long)BH * HIST * (QKB + DV / 4);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_ring_unpack, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)kx,
+                       (const _Float16*)vx, k_buf, v_buf, (long)T + HIST + KV_PAD, T, BH);
     return check_launch();
 }

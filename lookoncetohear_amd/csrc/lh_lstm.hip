@@ -684,7 +684,9 @@ static int cu_count() {
 }
 static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [3] 0 = no issue-priority de-phasing
 }
+namespace lh { int attn_set_mq(int v); }      // lh_attn.hip
 extern "C" int lh_set_tuning(int key, int value) {
+    if (key == 4) return lh::attn_set_mq(value);
     if (key < 0 || key >= 4) return LH_ERR_ARG;
     lh::g_tune[key] = value;
     if (key == 3) lh::g_dephase = value;

@@ -177,52 +177,116 @@ __device__ __forceinline__ void frame_zero_pad(_Float16* ahi, _Float16* alo, int
         store_split4<FR_RP>(ahi, alo, NF + (e >> 4), (e & 15) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-// One wave: LayerNorm over the NF*D values ys[f][col0 + e] (flat index i = f*D + e), affine per flat index, written
-// to dst[0..ld) (columns >= NF*D are zero padding).  Slot k of a lane is i = lane + 64k; out-of-range slots are
-// predicated (not clamped) so that for D = 16 every address is `base + k * constant` (immediate offsets, no
-// per-slot address registers kept live across the persistent frame loop).
-template <int D>
-__device__ __forceinline__ void ln_head(const float* ys, int yp, int col0, const float* __restrict__ gw,
-                                        const float* __restrict__ gb, float* __restrict__ dst, int ld, int lane) {
-    constexpr int N = NF * D;
-    constexpr int IT = (N + 63) / 64;              // 10 (Q/K) or 25 (V) slots per lane
-    auto at = [&](int k) -> float {
-        const int i = lane + 64 * k;
-        return i < N ? ys[(i / D) * yp + col0 + (i % D)] : 0.f;
-    };
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < IT; ++k) s += at(k);
-    const float mean = wave_sum(s) * (1.0f / N);
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < IT; ++k) {
-        const float dv = at(k) - mean;
-        if (lane + 64 * k < N) v += dv * dv;
-    }
-    const float rstd = rsqrtf(wave_sum(v) * (1.0f / N) + LN_EPS);
-#pragma unroll
-    for (int k = 0; k < IT; ++k) {
-        const int i = lane + 64 * k;
-        if (i < N) dst[i] = (at(k) - mean) * rstd * gw[i] + gb[i];
-        else if (i < ld) dst[i] = 0.f;             // pad columns (q/kx) stay 0
-    }
-}
+// Per-head LayerNorm + split-precision store, one wave per head (N values held flat, index i = f*D + e = the
+// reference's reshape order, in LDS at ysrc[0 .. 8*NOCT); entries >= N are zero; gw / gb are zero-padded to 8*NOCT so
+// pad outputs are exactly 0).  A lane owns octets lane + 64 k; out-of-range slots are clamped to the last octet (the
+// code stays branch-free so the affine loads of later slots are issued under the arithmetic of earlier ones) and
+// only their statistics contributions and stores are masked.  Output formats (lh_common.h):
+//   VLAYOUT = 0 (Q / K rows):  octet o -> [hi 8 | lo 8]
+//   VLAYOUT = 1 (V rows):      octet o -> quads 2o, 2o+1, each [hi 4 | lo 4]
+template <int N, int NOCT>
+struct HeadLN {
+    static constexpr int NS = (NOCT + 63) / 64;
+    float x[NS][8];
+    float4 w[NS][2], b[NS][2];
 
-// ------------------------------------------------------------------------------------------------------
-// Q/K/V projection + PReLU + per-head LayerNorm over (f,e); persistent workgroups, grid-stride over frames
-// ------------------------------------------------------------------------------------------------------
+    __device__ __forceinline__ static int oct(int lane, int k) { return min(lane + 64 * k, NOCT - 1); }
+    __device__ __forceinline__ static bool live(int lane, int k) { return lane + 64 * k < NOCT; }
+
+    // LDS -> registers; returns the lane's partial sum.  `zero8` = 8 floats of zeros in LDS (16-byte aligned): slots past
+    // the row read those instead, so nothing has to be masked out of the sum.
+    // All reads are drained (lgkmcnt(0)) before the first add.  With hipcc's own counted waits (lgkmcnt(3), (1), ...
+    // between the eight ds_read_b128 of a V row, most lanes of the last slot reading one shared address) about 0.3 %
+    // of the rows came out with a wrong mean on the MI355X — some adds consumed a register before its read had
+    // landed — whenever two workgroups shared a CU; run-to-run different, never on Q / K (scripts/gpu_determinism.py).
+    __device__ __forceinline__ float read(const float* ysrc, const float* zero8, int lane) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float* src = live(lane, k) ? ysrc + 8 * (lane + 64 * k) : zero8;
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 c = *reinterpret_cast<const float4*>(src + 4);
+            x[k][0] = a.x; x[k][1] = a.y; x[k][2] = a.z; x[k][3] = a.w;
+            x[k][4] = c.x; x[k][5] = c.y; x[k][6] = c.z; x[k][7] = c.w;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#if defined(__AMDGCN__)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[k][0]), "+v"(x[k][1]), "+v"(x[k][2]), "+v"(x[k][3]), "+v"(x[k][4]),
+                         "+v"(x[k][5]), "+v"(x[k][6]), "+v"(x[k][7]));
+#endif
+            s += (x[k][0] + x[k][1]) + (x[k][2] + x[k][3]) + (x[k][4] + x[k][5]) + (x[k][6] + x[k][7]);
+        }
+        return s;
+    }
+    __device__ __forceinline__ void load_affine(const float* __restrict__ gw, const float* __restrict__ gb, int lane) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int o = oct(lane, k);
+            w[k][0] = *reinterpret_cast<const float4*>(&gw[8 * o]);
+            w[k][1] = *reinterpret_cast<const float4*>(&gw[8 * o + 4]);
+            b[k][0] = *reinterpret_cast<const float4*>(&gb[8 * o]);
+            b[k][1] = *reinterpret_cast<const float4*>(&gb[8 * o + 4]);
+        }
+    }
+    __device__ __forceinline__ float center(float mean, int lane) {             // x -= mean; lane's partial sum of squares
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = x[k][e] - mean;
+                x[k][e] = d;
+                if (k < NS - 1 && 8 * (64 * k + 63) + 7 < N) v += d * d;            // slot entirely inside the row
+                else v += (8 * (lane + 64 * k) + e < N) ? d * d : 0.f;
+            }
+        return v;
+    }
+    // normalise + affine + split -> the row in global memory
+    template <int VLAYOUT>
+    __device__ __forceinline__ void store(float rstd, _Float16* dst, int lane) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float wv[8] = {w[k][0].x, w[k][0].y, w[k][0].z, w[k][0].w, w[k][1].x, w[k][1].y, w[k][1].z, w[k][1].w};
+            const float bv[8] = {b[k][0].x, b[k][0].y, b[k][0].z, b[k][0].w, b[k][1].x, b[k][1].y, b[k][1].z, b[k][1].w};
+            f16x8 h8, l8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = x[k][e] * rstd * wv[e] + bv[e];
+                const _Float16 h = (_Float16)y;
+                h8[e] = h;
+                l8[e] = (_Float16)((y - (float)h) * PW_SPLIT);
+            }
+            f16x8 o0 = h8, o1 = l8;
+            if (VLAYOUT) {
+                o0 = f16x8{h8[0], h8[1], h8[2], h8[3], l8[0], l8[1], l8[2], l8[3]};
+                o1 = f16x8{h8[4], h8[5], h8[6], h8[7], l8[4], l8[5], l8[6], l8[7]};
+            }
+            if (live(lane, k)) {
+                const int o = lane + 64 * k;
+                *reinterpret_cast<f16x8*>(&dst[16 * o]) = o0;
+                *reinterpret_cast<f16x8*>(&dst[16 * o + 8]) = o1;
+            }
+        }
+    }
+};
+// LDS image of the frame's projection outputs, already in each head's flat LayerNorm order:
+//   Q head h at [h * YQS + f*6 + e], K heads behind them, V head h at [Y_V0 + h * 1552 + f*16 + v]
+constexpr int YQS = DQKP + 8;              // head stride of the Q / K part (8 extra floats spread the heads over banks)
+constexpr int Y_K0 = NH * YQS;
+constexpr int Y_V0 = 2 * NH * YQS;
+constexpr int Y_N = Y_V0 + NH * DV;        // 11136 floats
+
 __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slopes,
                                                      const float* __restrict__ lnq_w, const float* __restrict__ lnq_b,
                                                      const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
                                                      const float* __restrict__ lnv_w, const float* __restrict__ lnv_b,
-                                                     float* __restrict__ q, float* __restrict__ kx,
-                                                     float* __restrict__ vx, int T, int nframes) {
-    constexpr int YP = NQKV + 1;          // 113: odd stride -> conflict-free column walks in the LN phase
+                                                     _Float16* __restrict__ q, _Float16* __restrict__ kx,
+                                                     _Float16* __restrict__ vx, int T, int nframes) {
     __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
-    __shared__ float ys[NF * YP];
+    __shared__ __attribute__((aligned(16))) float yf[Y_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
     // wave w owns output-column tiles w and w+4 (of 7): Q|K|V columns 16w.. and 64+16w..
@@ -234,14 +298,24 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     const float bz0 = bias[c0], bz1 = bias[two ? c1 : c0];
     const float sq = slopes[0], sk = slopes[1], sv = slopes[2];
     const float a0 = c0 < NH * E ? sq : (c0 < 2 * NH * E ? sk : sv);      // PReLU slope of column c0; c1 is always V
+    // where this lane's columns land in yf: element (f, c) -> base + f * stride
+    int base0, str0;
+    if (c0 < NH * E) { base0 = (c0 / E) * YQS + c0 % E; str0 = E; }
+    else if (c0 < 2 * NH * E) { base0 = Y_K0 + ((c0 - NH * E) / E) * YQS + (c0 - NH * E) % E; str0 = E; }
+    else { base0 = Y_V0 + ((c0 - 2 * NH * E) / VD) * DV + (c0 - 2 * NH * E) % VD; str0 = VD; }
+    const int cv = (two ? c1 : c0) - 2 * NH * E;                  // second tile: always V columns (unused when !two)
+    const int base1 = Y_V0 + (cv / VD) * DV + cv % VD;
 
     frame_zero_pad(ahi, alo, tid);
+    for (int i = tid; i < 2 * NH * (YQS - DQK); i += 256)      // pad entries 582.. of the Q / K heads stay zero
+        yf[(i / (YQS - DQK)) * YQS + DQK + i % (YQS - DQK)] = 0.f;
     float4 stg[FR_NLD];
     if ((int)blockIdx.x < nframes) frame_load(y + (long)blockIdx.x * NF * C, tid, stg);
+    const long tkp = T + HIST + KV_PAD;
     for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
         const int b = fr / T, t = fr % T;
         frame_store(ahi, alo, tid, stg);
-        __syncthreads();                      // image complete; also orders the previous frame's reads of `ys`
+        __syncthreads();                      // image complete; also orders the previous frame's reads of `yf`
         if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
 #pragma unroll 1
@@ -250,28 +324,52 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m * 16 + g4 * 4 + r;
-                if (row < NF) ys[row * YP + c0] = prelu_f(r0[r], a0);
+                if (row < NF) yf[base0 + row * str0] = prelu_f(r0[r], a0);
             }
             if (two) {
                 const f32x4 r1 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh1, wl1, bz1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m * 16 + g4 * 4 + r;
-                    if (row < NF) ys[row * YP + c1] = prelu_f(r1[r], sv);
+                    if (row < NF) yf[base1 + row * VD] = prelu_f(r1[r], sv);
                 }
             }
         }
         __syncthreads();
 
-        // per-head LayerNorm: wave w normalises head w of Q, K and V; flat index = f*D + e (F-major, e-minor)
+        // per-head LayerNorm: wave w normalises head w of Q, K and V and writes the split-precision rows
         const int hd = wave;
         const long bh = (long)b * NH + hd;
-        // `fr >> 30` is always 0 but ties the lane index to the loop variable: without it LICM hoists ~45 slot
-        // addresses per head out of the persistent frame loop and the kernel spills
+        float* yq = yf + hd * YQS;
+        float* yk = yf + Y_K0 + hd * YQS;
+        float* yv = yf + Y_V0 + hd * DV;
+        const float* zero8 = yf + DQKP - 8;          // features 600..607 of Q head 0: always zero
+        _Float16* qrow = q + (bh * T + t) * LDQKH;
+        _Float16* krow = kx + (bh * tkp + HIST + t) * LDQKH;
+        _Float16* vrow = vx + (bh * tkp + HIST + t) * LDVH;
+        // `fr >> 30` is always 0 but ties the lane index to the loop variable: without it LICM hoists every slot address
+        // of the three rows out of the persistent frame loop and the kernel spills
         const int ln = lane + (fr >> 30);
-        ln_head<E>(ys, YP, hd * E, lnq_w, lnq_b, q + (bh * T + t) * LDQK, LDQK, ln);
-        ln_head<E>(ys, YP, NH * E + hd * E, lnk_w, lnk_b, kx + (bh * (T + HIST) + HIST + t) * LDQK, LDQK, ln);
-        ln_head<VD>(ys, YP, 2 * NH * E + hd * VD, lnv_w, lnv_b, vx + (bh * (T + HIST) + HIST + t) * DV, DV, ln);
+        {   // Q and K together: two independent statistics chains
+            HeadLN<DQK, QKB> lq, lk;
+            lq.load_affine(lnq_w, lnq_b, ln);
+            lk.load_affine(lnk_w, lnk_b, ln);
+            const float sq1 = lq.read(yq, zero8, ln), sk1 = lk.read(yk, zero8, ln);
+            const float mq = wave_sum(sq1) * (1.0f / DQK), mk = wave_sum(sk1) * (1.0f / DQK);
+            const float vq = lq.center(mq, ln), vk = lk.center(mk, ln);
+            const float rq = rsqrtf(wave_sum(vq) * (1.0f / DQK) + LN_EPS), rk = rsqrtf(wave_sum(vk) * (1.0f / DQK) + LN_EPS);
+            lq.store<0>(rq, qrow, ln);
+            lk.store<0>(rk, krow, ln);
+        }
+        {
+            HeadLN<DV, DV / 8> lv;
+            lv.load_affine(lnv_w, lnv_b, ln);
+            const float sv1 = lv.read(yv, zero8, ln);
+            const float mv = wave_sum(sv1) * (1.0f / DV);
+            const float vv = lv.center(mv, ln);
+            const float rv = rsqrtf(wave_sum(vv) * (1.0f / DV) + LN_EPS);
+            lv.store<1>(rv, vrow, ln);
+        }
     }
 }
 
@@ -389,7 +487,7 @@ extern "C" int lh_linear_res(const float* h, const void* w_pk, const float* bias
 
 extern "C" int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const float* slopes,
                               const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
-                              const float* lnv_w, const float* lnv_b, float* q, float* kx, float* vx, int B, int T,
+                              const float* lnv_w, const float* lnv_b, void* q, void* kx, void* vx, int B, int T,
                               lh_stream_t stream) {
     using namespace lh;
     if (!y || !w_pk || !bias || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !q || !kx ||
@@ -397,8 +495,8 @@ extern "C" int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bia
         return LH_ERR_ARG;
     const int nframes = B * T;
     hipLaunchKernelGGL(k_qkv_proj_ln, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y,
-                       (const _Float16*)w_pk, bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, q, kx, vx, T,
-                       nframes);
+                       (const _Float16*)w_pk, bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, (_Float16*)q,
+                       (_Float16*)kx, (_Float16*)vx, T, nframes);
     return check_launch();
 }
 

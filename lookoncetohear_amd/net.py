@@ -31,7 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _cabi
-from .weights import pack_all
+from .weights import KV_PAD_ROWS, QK_PAD, pack_all, unsplit_qk, unsplit_v
 
 
 def mod_pad(x: torch.Tensor, chunk_size: int, pad: Tuple[int, int]):
@@ -232,10 +232,13 @@ class Net(nn.Module):
             F_, C_, nh = self.n_freqs, self.emb_dim, self.n_head
             e = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)
             hist = self.local_atten_len - 1
+            # q / kx / vx: split-precision fp16 rows (include/lookonce_hip.h); kx / vx carry KV_PAD_ROWS zero rows that
+            # only this allocation ever writes
+            z16 = lambda *s: torch.zeros(*s, device=device, dtype=torch.float16)
             ws = dict(xa=e(B, T, F_, C_), xb=e(B, T, F_, C_), xc=e(B, T, F_, C_), hbuf=e(B * T * F_, 2 * self.hidden),
-                      q=e(B * nh, T, 584), kx=torch.zeros(B * nh, T + hist, 584, device=device),
-                      vx=e(B * nh, T + hist, self.V_dim * F_), gain=e(B, F_, C_), gain_raw=e(B, F_ * C_),
-                      hist_dirty=True)
+                      q=z16(B * nh, T, 2 * QK_PAD), kx=z16(B * nh, T + hist + KV_PAD_ROWS, 2 * QK_PAD),
+                      vx=z16(B * nh, T + hist + KV_PAD_ROWS, 2 * self.V_dim * F_), gain=e(B, F_, C_),
+                      gain_raw=e(B, F_ * C_), hist_dirty=False)
             self._ws[key] = ws
         return ws
 
@@ -331,8 +334,7 @@ class Net(nn.Module):
                              H_, st)
                 # attention: history rows in, Q/K/V, local attention (head merge fused), projection + LN + residual
                 if not from_zero:
-                    ws["kx"][:, :hist, :self.E * F_].copy_(bs["K_buf"])
-                    ws["vx"][:, :hist].copy_(bs["V_buf"])
+                    lib.call("lh_ring_pack", P(c32(bs["K_buf"])), P(c32(bs["V_buf"])), P(ws["kx"]), P(ws["vx"]), Bn, T, st)
                     ws["hist_dirty"] = True
                 elif ws["hist_dirty"]:                      # history rows of the window-extended buffers back to zero
                     ws["kx"][:, :hist].zero_()
@@ -348,13 +350,14 @@ class Net(nn.Module):
                          Bn, T, st)
                 if want_state:
                     bs["h0"], bs["c0"] = hN, cN
-                    bs["K_buf"] = ws["kx"][:, T:T + hist, :self.E * F_].contiguous()
-                    bs["V_buf"] = ws["vx"][:, T:T + hist].contiguous()
+                    bs["K_buf"] = torch.empty(Bn * nh, hist, self.E * F_, device=dev, dtype=torch.float32)
+                    bs["V_buf"] = torch.empty(Bn * nh, hist, self.V_dim * F_, device=dev, dtype=torch.float32)
+                    lib.call("lh_ring_unpack", P(ws["kx"]), P(ws["vx"]), P(bs["K_buf"]), P(bs["V_buf"]), Bn, T, st)
                 if taps is not None:
                     taps[f"blocks.{i}.Y2"] = xc.clone()
-                    taps[f"blocks.{i}.Q"] = ws["q"][:, :, :self.E * F_].clone()
-                    taps[f"blocks.{i}.K"] = ws["kx"][:, hist:, :self.E * F_].clone()
-                    taps[f"blocks.{i}.V"] = ws["vx"][:, hist:].clone()
+                    taps[f"blocks.{i}.Q"] = unsplit_qk(ws["q"], self.E * F_)
+                    taps[f"blocks.{i}.K"] = unsplit_qk(ws["kx"][:, hist:hist + T], self.E * F_)
+                    taps[f"blocks.{i}.V"] = unsplit_v(ws["vx"][:, hist:hist + T])
                     taps[f"blocks.{i}.out"] = xa.clone()
 
             dec_in, ist_in = c32(state["deconv_buf"]), c32(state["istft_buf"])

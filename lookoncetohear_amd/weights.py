@@ -10,6 +10,22 @@ from __future__ import annotations
 
 import torch
 
+QK_PAD = 608          # Q / K feature rows padded 582 -> 608 (76 blocks of 8; lh_common.h DQKP)
+KV_PAD_ROWS = 48      # zero rows behind the T+49 rows of kx / vx (include/lookonce_hip.h LH_KV_PAD_ROWS)
+SPLIT_SCALE = 2048.0
+
+
+def unsplit_qk(rows: torch.Tensor, n: int = 582) -> torch.Tensor:
+    """Split-precision q / kx rows [..., 1216] fp16 ([76 blocks][hi 8 | lo 8]) -> fp32 [..., n] (hi + 2^-11 lo)."""
+    r = rows.reshape(*rows.shape[:-1], QK_PAD // 8, 2, 8).float()
+    return (r[..., 0, :] + r[..., 1, :] / SPLIT_SCALE).reshape(*rows.shape[:-1], QK_PAD)[..., :n]
+
+
+def unsplit_v(rows: torch.Tensor) -> torch.Tensor:
+    """Split-precision vx rows [..., 3104] fp16 ([388 quads][hi 4 | lo 4]) -> fp32 [..., 1552]."""
+    r = rows.reshape(*rows.shape[:-1], rows.shape[-1] // 8, 2, 4).float()
+    return (r[..., 0, :] + r[..., 1, :] / SPLIT_SCALE).reshape(*rows.shape[:-1], rows.shape[-1] // 2)
+
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:
     """w [N, K] (nn.Linear weight) -> [N/16, K/4, 64] fp32 B-operand image."""
@@ -121,8 +137,10 @@ def pack_block(sd: dict, pre: str) -> dict:
     out["qkv_b"] = torch.cat([g("attn_conv_Q.0.bias"), g("attn_conv_K.0.bias"), g("attn_conv_V.0.bias")])
     out["qkv_slopes"] = torch.cat([g("attn_conv_Q.1.weight"), g("attn_conv_K.1.weight"), g("attn_conv_V.1.weight")])
     for nm in "QKV":
-        out[f"ln{nm.lower()}_w"] = g(f"attn_conv_{nm}.3.norm.weight")
-        out[f"ln{nm.lower()}_b"] = g(f"attn_conv_{nm}.3.norm.bias")
+        # Q / K affines zero-padded 582 -> 608: the kernel's pad features then come out as exact zeros
+        padn = (QK_PAD - g(f"attn_conv_{nm}.3.norm.weight").numel()) if nm != "V" else 0
+        out[f"ln{nm.lower()}_w"] = torch.nn.functional.pad(g(f"attn_conv_{nm}.3.norm.weight"), (0, padn))
+        out[f"ln{nm.lower()}_b"] = torch.nn.functional.pad(g(f"attn_conv_{nm}.3.norm.bias"), (0, padn))
     out["proj_w"], out["proj_b"] = pack_linear_f16x3(g("attn_concat_proj.0.weight")), g("attn_concat_proj.0.bias")
     out["proj_slope"] = g("attn_concat_proj.1.weight")
     out["proj_ln_w"], out["proj_ln_b"] = g("attn_concat_proj.3.norm.weight"), g("attn_concat_proj.3.norm.bias")

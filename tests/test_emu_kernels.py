@@ -71,6 +71,51 @@ def test_streaming_chunks_and_mod_pad(emu_net, oracle_cfg_sd):
     assert y.shape == yo.shape == (1, 2, 300) and (y - yo).abs().max() < TOL
 
 
+def test_attention_tile_modes_multi_tile(emu_net, oracle_cfg_sd):
+    """T = 37 with non-zero state: three 16-frame tiles (one query tile per workgroup) and two 32-frame tiles (two query
+    tiles sharing their K / V rows, the default for T > 16), last tile ragged in both; outputs and the next state
+    (K_buf / V_buf through lh_ring_unpack) against the oracle."""
+    cfg, sd = oracle_cfg_sd
+    lib = emu_net._lib_override
+    B, T = 1, 37
+    d = synth.batch([7], 128 * T + 64)
+    st = O.random_state(cfg, B, 5)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    fo = O.flat_state(so)
+    try:
+        for mode in (1, 2):
+            lib.call("lh_set_tuning", 4, mode)
+            y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+            assert (y - yo).abs().max() < TOL, mode
+            fm = O.flat_state(s2)
+            for k in fo:
+                assert fm[k].shape == fo[k].shape and (fm[k] - fo[k]).abs().max() < TOL, (mode, k)
+        assert lib.raw("lh_set_tuning")(4, 3) == 1           # LH_ERR_ARG
+    finally:
+        lib.call("lh_set_tuning", 4, 2)
+
+
+def test_ring_pack_unpack_roundtrip(emu_net):
+    """fp32 state -> split-precision history rows -> fp32: hi + 2^-11 lo keeps 22 bits (|err| <= 2^-22 |v| + tiny)."""
+    from lookoncetohear_amd.weights import KV_PAD_ROWS, QK_PAD, unsplit_qk, unsplit_v
+    lib = emu_net._lib_override
+    B, T = 1, 3
+    g = torch.Generator().manual_seed(9)
+    kb = torch.randn(4 * B, 49, 582, generator=g) * 3
+    vb = torch.randn(4 * B, 49, 1552, generator=g) * 3
+    kx = torch.zeros(4 * B, T + 49 + KV_PAD_ROWS, 2 * QK_PAD, dtype=torch.float16)
+    vx = torch.zeros(4 * B, T + 49 + KV_PAD_ROWS, 2 * 1552, dtype=torch.float16)
+    lib.call("lh_ring_pack", kb.data_ptr(), vb.data_ptr(), kx.data_ptr(), vx.data_ptr(), B, T, None)
+    assert (unsplit_qk(kx[:, :49]) - kb).abs().max() < 3 * 2.0 ** -21 and (unsplit_v(vx[:, :49]) - vb).abs().max() < 3 * 2.0 ** -21
+    assert kx[:, 49:].abs().max() == 0 and vx[:, 49:].abs().max() == 0            # nothing else touched
+    # rows T .. T+48 are what lh_ring_unpack reads: place the packed rows there and read them back
+    krows, vrows = kx[:, :49].clone(), vx[:, :49].clone()
+    kx[:, T:T + 49], vx[:, T:T + 49] = krows, vrows
+    k2, v2 = torch.empty_like(kb), torch.empty_like(vb)
+    lib.call("lh_ring_unpack", kx.data_ptr(), vx.data_ptr(), k2.data_ptr(), v2.data_ptr(), B, T, None)
+    assert torch.equal(k2, unsplit_qk(krows)) and torch.equal(v2, unsplit_v(vrows))
+
+
 def test_cabi_argument_errors(emu_net):
     lib = emu_net._lib_override
     assert lib.raw("lh_check_config")(192, 128, 2, 64, 3, 64, 4, 50, 2, 256) == 0
