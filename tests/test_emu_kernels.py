@@ -71,6 +71,26 @@ def test_streaming_chunks_and_mod_pad(emu_net, oracle_cfg_sd):
     assert y.shape == yo.shape == (1, 2, 300) and (y - yo).abs().max() < TOL
 
 
+def test_fused_intra_path_forced_small(emu_net, oracle_cfg_sd):
+    """The large-batch intra path (LSTM + Linear + residual fused, forward launch then accumulating reverse launch),
+    which `Net` only selects from 8192 frames on, forced at a tiny size: 38 frames = 3 sequence tiles, last one ragged."""
+    cfg, sd = oracle_cfg_sd
+    B, T = 2, 19
+    d = synth.batch([3, 4], 128 * T + 64)
+    st = O.random_state(cfg, B, 3)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    saved = emu_net.fuse_intra_min_frames
+    emu_net.fuse_intra_min_frames = 1
+    try:
+        y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    finally:
+        emu_net.fuse_intra_min_frames = saved
+    assert (y - yo).abs().max() < TOL
+    fo, fm = O.flat_state(so), O.flat_state(s2)
+    for k in fo:
+        assert (fm[k] - fo[k]).abs().max() < TOL, k
+
+
 def test_attention_tile_modes_multi_tile(emu_net, oracle_cfg_sd):
     """T = 37 with non-zero state: three 16-frame tiles (one query tile per workgroup) and two 32-frame tiles (two query
     tiles sharing their K / V rows, the default for T > 16), last tile ragged in both; outputs and the next state
