@@ -170,12 +170,13 @@ int lh_proj_ln_res(const float* merged, const void* w_pk, const float* bias, con
 /* A.4  causal ConvTranspose2d(64->4,3x3) + spectrum re-pack + iSTFT synthesis/overlap-add.
  * Replaces tfgridnet_causal.py:256-273 and the look-ahead trim of net.py:61.
  *   y [B][T][97][64]; deconv_buf_in/out [B][64][2][97]; istft_buf_in/out [B][2][194][1]
- *   wdec_pk fp32 MFMA B image [3 tiles][16 ksteps][64 lanes] of deconv.weight as [64 c] x [(kt,kf,o) 36 -> 48];
- *   bdec [4]; wfb_dec fp32 MFMA B image [12 tiles][52 ksteps][64 lanes] of dec.filterbank._filters [194 -> 208 x 192]
+ *   wdec_pk fp16 hi/lo B image [3 ntiles][2 ksteps][64 lanes][16] of deconv.weight as [(kt,kf,o) 36 -> 48] x [64 c];
+ *   bdec [4]; wfb_dec fp16 hi/lo B image [12 ntiles][7 ksteps][64 lanes][16] of dec.filterbank._filters^T
+ *   [192 samples] x [194 -> 224 rows]   (weights.py pack_linear_f16x3)
  *   wave_out [B][2][128*T]
  */
 int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out, const float* istft_buf_in,
-                    float* istft_buf_out, const float* wdec_pk, const float* bdec, const float* wfb_dec,
+                    float* istft_buf_out, const void* wdec_pk, const float* bdec, const void* wfb_dec,
                     float* wave_out, int B, int T, lh_stream_t stream);
 
 /* ---- enrollment embedder (reference src/models/tfgridnet_orig/tfgridnet.py:88-127 + espnet2 TF-GridNet trunk) ----

@@ -1,59 +1,60 @@
 // Back end of the separator: causal ConvTranspose2d(64->4, 3x3) + re/im re-pack + iSTFT synthesis with
-// overlap-add and carried tails on exact fp32 MFMA, persistent
-// workgroups.
+// overlap-add and carried tails, persistent workgroups of 8 waves.
 //
 // The transposed conv is factored so that every input frame is read from HBM once and multiplied once:
-//     P[fr][f'][(kt,kf,o)] = sum_c Y[fr][f'][c] * Wd[c][o][kt][kf]          ([97 x 64] x [64 x 36] MFMA per frame)
+//     P[fr][f'][(kt,kf,o)] = sum_c Y[fr][f'][c] * Wd[c][o][kt][kf]          ([97 x 64] x [64 x 36] per frame)
 //     D[t][o][f]           = b[o] + sum_{kt,kf} P[t-kt][f+1-kf][(kt,kf,o)]   (9-term gather-add from a 3-frame ring)
-// A tile = 15 output frames of one utterance: 18 input frames (3 halo) stream through a register-staged LDS
-// image, the 16 spectra Sx[t0..t0+15] (Sx[0] = carried istft_buf) are assembled in LDS, and the synthesis
-// filterbank ([194 x 192], resident in VGPRs as MFMA B fragments for the whole kernel) turns them into 16
-// frames per source that are overlap-added into 15 x 128 output samples.
-#include "lh_common.h"
+// A tile = 15 output frames of one utterance: 18 input frames (3 halo) stream through a register-staged LDS image,
+// the 16 spectra Sx[t0..t0+15] (Sx[0] = carried istft_buf) are assembled in LDS as a second A image, and the
+// synthesis filterbank ([194 x 192], resident in VGPRs as B fragments for the whole kernel) turns them into 16 frames
+// per source that are overlap-added into 15 x 128 output samples.
+// Both contractions run on split-precision fp16 MFMA (v = hi + 2^-11 lo, three v_mfma_f32_16x16x32_f16 per product,
+// lh_split.h): the exact-fp32 MFMA version of this kernel spent 5x the matrix cycles and, at one wave per SIMD
+// (386 registers), could not hide them: 0.46 ms per call at B = 32 against an HBM floor of 0.08 ms.
+#include "lh_split.h"
 
 namespace lh {
 
+constexpr int BE_NT = 512;                // threads per workgroup (8 waves, two per SIMD)
 constexpr int BE_TT = 15;                 // output frames per tile
 constexpr int BE_NJ = BE_TT + 1;          // Sx frames t0 .. t0+15 (one MFMA row tile per source)
-constexpr int BE_YP = 20;                 // Y image: 16-float k-chunk + 4 pad
-constexpr int BE_RP = 112;                // 7 row tiles cover 97 bins
-constexpr int BE_NP = 48;                 // 36 partial-product columns (kt,kf,o) padded to 3 column tiles
+constexpr int BE_NP = 36;                 // partial-product columns (kt,kf,o); the B image pads them to 48
 constexpr int BE_PP = BE_NP + 1;          // P row stride (odd: conflict-free gather)
-constexpr int BE_KC = 52;                 // synthesis k-chunk per 16-lane group (194 -> 208 = 4 x 52)
-constexpr int BE_SP = BE_KC + 4;          // Sx image chunk row (14 x 16 B)
+constexpr int BE_SK = 7;                  // synthesis k-steps: 194 spectrum rows -> 224
+constexpr int BE_SA = BE_SK * 4 * BE_NJ * 8;   // halves per source in the Sx A image
 constexpr int BE_FP = NFFT + 4;           // synthesis frame staging row
+constexpr int BE_NLD = (NF * 16 + BE_NT - 1) / BE_NT;   // float4 per thread and frame (4)
+constexpr int BE_RING = 4;                // input frames in flight per workgroup
 
-// grid = persistent (<= 256), block 256
-__global__ void __launch_bounds__(256, 1) k_deconv_istft(const float* __restrict__ y, const float* __restrict__ dbuf_in,
-                                                         float* __restrict__ dbuf_out, const float* __restrict__ ibuf_in,
-                                                         float* __restrict__ ibuf_out, const float* __restrict__ wd_pk,
-                                                         const float* __restrict__ bd, const float* __restrict__ wfb_pk,
-                                                         float* __restrict__ wave_out, int B, int T) {
-    __shared__ __attribute__((aligned(16))) float yimg[4 * BE_RP * BE_YP];          // A image of one input frame
+// grid = persistent (<= 256), block 512
+__global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict__ y, const float* __restrict__ dbuf_in,
+                                                        float* __restrict__ dbuf_out, const float* __restrict__ ibuf_in,
+                                                        float* __restrict__ ibuf_out, const _Float16* __restrict__ wd_pk,
+                                                        const float* __restrict__ bd, const _Float16* __restrict__ wfb_pk,
+                                                        float* __restrict__ wave_out, int B, int T) {
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];                     // A image of one input frame
+    __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ float pring[3][NF][BE_PP];                                           // partial products of 3 frames
-    __shared__ __attribute__((aligned(16))) float sximg[NSRC * 4 * BE_NJ * BE_SP];  // A image of the 16 spectra
+    __shared__ __attribute__((aligned(16))) _Float16 sxh[NSRC * BE_SA];             // A image of the 16 spectra
+    __shared__ __attribute__((aligned(16))) _Float16 sxl[NSRC * BE_SA];
     __shared__ __attribute__((aligned(16))) float frs[BE_NJ][NSRC][BE_FP];          // synthesis frames
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
-    // resident B fragments: deconv taps [64 x 48] (3 column tiles), synthesis filterbank tiles w, w+4, w+8
-    float wd[3][16];
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) wd[nt][ks] = wd_pk[(nt * 16 + ks) * 64 + lane];
-    float wf[3][BE_KC];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int ks = 0; ks < BE_KC; ++ks) wf[i][ks] = wfb_pk[((long)(wave + 4 * i) * BE_KC + ks) * 64 + lane];
+    // B fragments: the deconv taps [64 -> 48 columns] (3 column tiles x 2 k-steps, 6 KB) sit in LDS in fragment order;
+    // the synthesis filterbank tiles 2w, 2w+1 (of 12; 112 registers) are fetched from L2 once per tile, right before
+    // they are used — the registers hold the frame prefetch ring while the frames stream
+    __shared__ __attribute__((aligned(16))) _Float16 wds[3 * 2 * 64 * 16];
+    for (int i = tid; i < 3 * 2 * 64 * 2; i += BE_NT)
+        *reinterpret_cast<f16x8*>(&wds[i * 8]) = *reinterpret_cast<const f16x8*>(&wd_pk[i * 8]);
+    const bool synth = wave < 6;
     float bias4[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) bias4[o] = bd[o];
 
-    // zero the rows / k-padding of the A images that are never written (they only feed dropped outputs, but must
-    // be finite)
-    for (int i = tid; i < 4 * BE_RP * BE_YP; i += 256) yimg[i] = 0.f;
-    for (int i = tid; i < NSRC * 4 * BE_NJ * BE_SP; i += 256) sximg[i] = 0.f;
+    // rows / k-padding of the A images that are never written only feed dropped outputs or multiply zero weights,
+    // but must be finite
+    for (int i = tid; i < FR_A; i += BE_NT) { ahi[i] = (_Float16)0.f; alo[i] = (_Float16)0.f; }
+    for (int i = tid; i < NSRC * BE_SA; i += BE_NT) { sxh[i] = (_Float16)0.f; sxl[i] = (_Float16)0.f; }
 
     const int tiles_per_b = (T + BE_TT - 1) / BE_TT;
     const long L = (long)HOP * T;
@@ -63,66 +64,68 @@ __global__ void __launch_bounds__(256, 1) k_deconv_istft(const float* __restrict
         const int nt_out = min(BE_TT, T - t0);
         __syncthreads();
 
+        // one spectrum value -> row jd of source s's A image
+        auto put_sx = [&](int jd, int s, int k, float v) {
+            const _Float16 h = (_Float16)v;
+            const int idx = s * BE_SA + a_index<BE_NJ>(jd, k);
+            sxh[idx] = h;
+            sxl[idx] = (_Float16)((v - (float)h) * PW_SPLIT);
+        };
         // Sx frame 0 of the very first tile is the carried spectrum of the previous call
         if (t0 == 0)
-            for (int i = tid; i < NSRC * NK; i += 256) {
-                const int s = i / NK, k = i % NK;
-                sximg[((s * 4 + k / BE_KC) * BE_NJ + 0) * BE_SP + k % BE_KC] = ibuf_in[(long)b * NSRC * NK + i];
-            }
+            for (int i = tid; i < NSRC * NK; i += BE_NT) put_sx(0, i / NK, i % NK, ibuf_in[(long)b * NSRC * NK + i]);
 
         // input frames t0-3 .. t0+nt_out-1 ; after frame fr has been multiplied, output frame td = fr is complete
-        float4 stg[7];
-        auto load_frame = [&](int fr) {
+        float4 stg[BE_RING][BE_NLD];
+        auto load_frame = [&](int fr, float4 (&dst)[BE_NLD]) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const int e = min(tid + 256 * i, NF * 16 - 1), f = e >> 4, c4 = e & 15;
+            for (int i = 0; i < BE_NLD; ++i) {
+                const int e = min(tid + BE_NT * i, NF * 16 - 1), f = e >> 4, c4 = e & 15;
                 if (fr >= 0) {
-                    stg[i] = *reinterpret_cast<const float4*>(&y[(((long)b * T + fr) * NF + f) * C + c4 * 4]);
+                    dst[i] = *reinterpret_cast<const float4*>(&y[(((long)b * T + fr) * NF + f) * C + c4 * 4]);
                 } else {                              // carried halo frames, layout [B][64][2][97]
                     const float* d0 = &dbuf_in[(((long)b * C + c4 * 4) * 2 + (fr + 2)) * NF + f];
-                    stg[i] = make_float4(d0[0], d0[2 * NF], d0[4 * NF], d0[6 * NF]);
+                    dst[i] = make_float4(d0[0], d0[2 * NF], d0[4 * NF], d0[6 * NF]);
                 }
             }
         };
         const int fr_first = max(t0 - 3, -2);         // frames below -2 do not exist (their taps see nothing)
-        load_frame(fr_first);
-        for (int fr = fr_first; fr < t0 + nt_out; ++fr) {
-            // stage frame fr into the A image, prefetch the next one
+        const int fr_end = t0 + nt_out;
+        // BE_RING frames in flight per workgroup: with a single one the loop ran at one HBM round trip per frame
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const int e = tid + 256 * i;
-                if (e < NF * 16) {
-                    const int f = e >> 4, c4 = e & 15;
-                    *reinterpret_cast<float4*>(&yimg[((c4 >> 2) * BE_RP + f) * BE_YP + (c4 & 3) * 4]) = stg[i];
-                }
+        for (int u = 0; u < BE_RING; ++u)
+            if (fr_first + u < fr_end) load_frame(fr_first + u, stg[u]);
+        for (int fbase = fr_first; fbase < fr_end; fbase += BE_RING) {
+#pragma unroll
+          for (int u = 0; u < BE_RING; ++u) {
+            const int fr = fbase + u;
+            if (fr >= fr_end) break;
+            // stage frame fr into the A image, refill its ring slot
+#pragma unroll
+            for (int i = 0; i < BE_NLD; ++i) {
+                const int e = tid + BE_NT * i;
+                if (e < NF * 16) store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[u][i]);
             }
             __syncthreads();
-            if (fr + 1 < t0 + nt_out) load_frame(fr + 1);
+            if (fr + BE_RING < fr_end) load_frame(fr + BE_RING, stg[u]);
 
-            // P[fr] = Y[fr] (97 x 64) * Wd (64 x 48): wave w takes row tiles w and w+4
+            // P[fr] = Y[fr] (97 x 64) * Wd (64 x 48): 21 (row tile, column tile) products over the 8 waves
             const int slot = ((fr % 3) + 3) % 3;
-            for (int mt = wave; mt < 7; mt += 4) {
-                f32x4 acc[3];
+            for (int p = wave; p < 21; p += 8) {
+                const int mt = p / 3, nt = p % 3;
+                f16x8 wh[2], wl[2];
 #pragma unroll
-                for (int nt = 0; nt < 3; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float* arow = &yimg[(g4 * BE_RP + mt * 16 + l15) * BE_YP];
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
-                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < 3; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wd[nt][qq * 4 + j], acc[nt], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    wh[ks] = *reinterpret_cast<const f16x8*>(&wds[((nt * 2 + ks) * 64 + lane) * 16]);
+                    wl[ks] = *reinterpret_cast<const f16x8*>(&wds[((nt * 2 + ks) * 64 + lane) * 16 + 8]);
                 }
+                const f32x4 acc = mma_tile<FR_RP, 2>(ahi, alo, mt, g4, l15, wh, wl, 0.f);
+                const int col = nt * 16 + l15;
 #pragma unroll
-                for (int nt = 0; nt < 3; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = mt * 16 + g4 * 4 + r;
-                        if (f < NF) pring[slot][f][nt * 16 + l15] = acc[nt][r];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int f = mt * 16 + g4 * 4 + r;
+                    if (f < NF && col < BE_NP) pring[slot][f][col] = acc[r];
+                }
             }
             __syncthreads();
 
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256, 1) k_deconv_istft(const float* __restrict
             const int td = fr;
             if (td >= t0 - 1 && td >= 0) {
                 const int jd = td + 1 - t0;           // Sx frame index inside the tile
-                for (int i = tid; i < 4 * NF; i += 256) {
+                for (int i = tid; i < 4 * NF; i += BE_NT) {
                     const int o = i & 3, f = i >> 2;
                     float v = bias4[o];
 #pragma unroll
@@ -145,51 +148,45 @@ __global__ void __launch_bounds__(256, 1) k_deconv_istft(const float* __restrict
                         }
                     }
                     const int s = o >> 1, k = (o & 1) * NF + f;
-                    sximg[((s * 4 + k / BE_KC) * BE_NJ + jd) * BE_SP + k % BE_KC] = v;
+                    put_sx(jd, s, k, v);
+                    if (td == T - 1) ibuf_out[((long)b * NSRC + s) * NK + k] = v;      // new carried spectrum (exact fp32)
                 }
             }
             // the next iteration's staging barrier orders these pring reads before the slot is overwritten 3 frames later
+          }
         }
         __syncthreads();
 
-        // new carried state (last tile only)
+        // new carried conv halo (last tile only)
         if (t0 + nt_out == T) {
-            for (int i = tid; i < 2 * NF * C; i += 256) {
+            for (int i = tid; i < 2 * NF * C; i += BE_NT) {
                 const int c = i % C, f = (i / C) % NF, r = i / (C * NF);
                 const int fr = T - 2 + r;
                 const float v = fr >= 0 ? y[(((long)b * T + fr) * NF + f) * C + c]
                                         : dbuf_in[(((long)b * C + c) * 2 + (fr + 2)) * NF + f];
                 dbuf_out[(((long)b * C + c) * 2 + r) * NF + f] = v;
             }
-            for (int i = tid; i < NSRC * NK; i += 256) {
-                const int s = i / NK, k = i % NK;
-                ibuf_out[(long)b * NSRC * NK + i] = sximg[((s * 4 + k / BE_KC) * BE_NJ + nt_out) * BE_SP + k % BE_KC];
-            }
         }
 
-        // synthesis: fr[jd][s][n] = sum_k Sx[jd][s][k] Wdec[k][n]; row tile = source, 12 column tiles of 16 samples
+        // synthesis: fr[jd][s][n] = sum_k Sx[jd][s][k] Wdec[k][n]; row tile = the 16 frames of a source, waves 0..5
+        // own 2 of the 12 column tiles of 16 samples each
+        if (synth) {
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {             // one column tile at a time: 56 registers of B fragments
+                f16x8 wfh[BE_SK], wfl[BE_SK];
+                load_w<BE_SK>(wfb_pk, 2 * wave + i, lane, wfh, wfl);
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) {
-            float av[BE_KC];
-            const float* arow = &sximg[((s * 4 + g4) * BE_NJ + l15) * BE_SP];
+                for (int s = 0; s < NSRC; ++s) {
+                    const f32x4 acc = mma_tile<BE_NJ, BE_SK>(sxh + s * BE_SA, sxl + s * BE_SA, 0, g4, l15, wfh, wfl, 0.f);
 #pragma unroll
-            for (int qq = 0; qq < BE_KC / 4; ++qq) {
-                const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
-                av[qq * 4 + 0] = a4.x; av[qq * 4 + 1] = a4.y; av[qq * 4 + 2] = a4.z; av[qq * 4 + 3] = a4.w;
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < BE_KC; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wf[i][ks], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) frs[g4 * 4 + r][s][(wave + 4 * i) * 16 + l15] = acc[r];
+                    for (int r = 0; r < 4; ++r) frs[g4 * 4 + r][s][(2 * wave + i) * 16 + l15] = acc[r];
+                }
             }
         }
         __syncthreads();
 
         // overlap-add: output frame t (samples 128t..128t+127) = fr[t+1][0:128] + fr[t][128:192]
-        for (int i = tid; i < nt_out * NSRC * HOP; i += 256) {
+        for (int i = tid; i < nt_out * NSRC * HOP; i += BE_NT) {
             const int n = i % HOP, s = (i / HOP) % NSRC, jt = i / (HOP * NSRC);
             float v = frs[jt + 1][s][n];
             if (n < NFFT - HOP) v += frs[jt][s][n + HOP];
@@ -201,8 +198,8 @@ __global__ void __launch_bounds__(256, 1) k_deconv_istft(const float* __restrict
 }  // namespace lh
 
 extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out,
-                               const float* istft_buf_in, float* istft_buf_out, const float* wdec_pk,
-                               const float* bdec, const float* wfb_dec, float* wave_out, int B, int T,
+                               const float* istft_buf_in, float* istft_buf_out, const void* wdec_pk,
+                               const float* bdec, const void* wfb_dec, float* wave_out, int B, int T,
                                lh_stream_t stream) {
     using namespace lh;
     if (!y || !deconv_buf_in || !deconv_buf_out || !istft_buf_in || !istft_buf_out || !wdec_pk || !bdec || !wfb_dec ||
@@ -210,7 +207,8 @@ extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float
         return LH_ERR_ARG;
     if (deconv_buf_in == deconv_buf_out || istft_buf_in == istft_buf_out) return LH_ERR_ARG;
     const int tiles = B * ((T + BE_TT - 1) / BE_TT);
-    hipLaunchKernelGGL(k_deconv_istft, dim3(tiles < 256 ? tiles : 256), dim3(256), 0, (hipStream_t)stream, y,
-                       deconv_buf_in, deconv_buf_out, istft_buf_in, istft_buf_out, wdec_pk, bdec, wfb_dec, wave_out, B, T);
+    hipLaunchKernelGGL(k_deconv_istft, dim3(tiles < 256 ? tiles : 256), dim3(BE_NT), 0, (hipStream_t)stream, y,
+                       deconv_buf_in, deconv_buf_out, istft_buf_in, istft_buf_out, (const _Float16*)wdec_pk, bdec,
+                       (const _Float16*)wfb_dec, wave_out, B, T);
     return check_launch();
 }

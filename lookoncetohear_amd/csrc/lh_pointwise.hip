@@ -14,70 +14,9 @@
 //   * each WAVE owns output-column tiles (not row tiles): its weight fragments are 16-32 registers instead of
 //     112-128, which keeps 2-3 workgroups resident per CU for latency hiding;
 //   * LayerNorm / PReLU / residual epilogues run out of LDS with compile-time index algebra.
-#include "lh_common.h"
+#include "lh_split.h"
 
 namespace lh {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-constexpr float PW_SPLIT = 2048.0f;
-
-// A-operand LDS image for v_mfma_f32_16x16x32_f16: [block = kstep*4 + 16-lane group][row slot][8 halves].
-// Reads: a lane's 16 bytes of consecutive rows are consecutive 16-byte slots.  Writes come row-major from the
-// coalesced global loads (16 lanes = one row = 8 blocks x 2 halves), and the block stride is a multiple of
-// 128 bytes, so the row slot is XOR-swizzled with the block index: the 8 blocks of one row land in 8 different
-// slots (conflict-free ds_write_b64), while within any ds_read_b128 lane group the XOR only permutes rows
-// inside aligned groups of 4 (or swaps the two halves of the group), which keeps the reads conflict-free.
-template <int RP>
-__device__ __forceinline__ int a_slot(int blk, int row) { return (blk * RP + (row ^ (blk & 7))) * 8; }
-template <int RP>
-__device__ __forceinline__ int a_index(int row, int k) {
-    return a_slot<RP>((k >> 5) * 4 + ((k >> 3) & 3), row) + (k & 7);
-}
-
-template <int RP>
-__device__ __forceinline__ void store_split4(_Float16* ahi, _Float16* alo, int row, int k0, float4 v) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    f16x4 h4, l4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const _Float16 h = (_Float16)x[i];
-        h4[i] = h;
-        l4[i] = (_Float16)((x[i] - (float)h) * PW_SPLIT);
-    }
-    const int idx = a_index<RP>(row, k0);
-    *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
-    *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
-}
-
-// bias + A[m-tile rows] * W[n-tile]  for K = 32*KS; wh/wl = hi/lo B fragments of this wave's n-tile
-template <int RP, int KS>
-__device__ __forceinline__ f32x4 mma_tile(const _Float16* ahi, const _Float16* alo, int m, int g4, int l15,
-                                          const f16x8 (&wh)[KS], const f16x8 (&wl)[KS], float bias) {
-    f32x4 am = f32x4{bias, bias, bias, bias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int idx = a_slot<RP>(ks * 4 + g4, m * 16 + l15);
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
-        const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
-        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
-    }
-    return am + ac * (1.0f / PW_SPLIT);
-}
-
-// weight image: [n-tile][kstep][lane][hi 8 | lo 8] fp16 (weights.py: pack_linear_f16x3)
-template <int KS>
-__device__ __forceinline__ void load_w(const _Float16* __restrict__ w_pk, int nt, int lane, f16x8 (&wh)[KS],
-                                       f16x8 (&wl)[KS]) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const _Float16* p = w_pk + ((long)(nt * KS + ks) * 64 + lane) * 16;
-        wh[ks] = *reinterpret_cast<const f16x8*>(p);
-        wl[ks] = *reinterpret_cast<const f16x8*>(p + 8);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------
 // out[r][0:64] = res[r][0:64] + bias + sum_k h[r][k] * W[o][k]       K in {64, 128}; 64-row tiles
@@ -140,41 +79,6 @@ __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h,
         }
         // the next tile's staging barrier orders these cs reads before cs is rewritten
     }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// frame staging shared by the two frame kernels: [97 x 64] fp32 -> hi/lo fp16 A image (rows padded to 112)
-// ------------------------------------------------------------------------------------------------------
-constexpr int FR_RP = 112;
-constexpr int FR_A = 2 * 4 * FR_RP * 8;    // halves per image (K = 64 -> 2 k-steps)
-constexpr int FR_NLD = (NF * 16 + 255) / 256;
-
-__device__ __forceinline__ void frame_load(const float* __restrict__ src, int tid, float4 (&stg)[FR_NLD]) {
-#pragma unroll
-    for (int i = 0; i < FR_NLD; ++i) {
-        const int e = min(tid + 256 * i, NF * 16 - 1);
-        stg[i] = *reinterpret_cast<const float4*>(&src[(e >> 4) * C + (e & 15) * 4]);
-    }
-}
-// same, from the attention kernel's head-major frame [4 heads][97][16]: channel c = head*16 + v
-__device__ __forceinline__ void frame_load_heads(const float* __restrict__ src, int tid, float4 (&stg)[FR_NLD]) {
-#pragma unroll
-    for (int i = 0; i < FR_NLD; ++i) {
-        const int e = min(tid + 256 * i, NF * 16 - 1);
-        stg[i] = *reinterpret_cast<const float4*>(&src[((e & 15) >> 2) * DV + (e >> 4) * VD + (e & 3) * 4]);
-    }
-}
-__device__ __forceinline__ void frame_store(_Float16* ahi, _Float16* alo, int tid, const float4 (&stg)[FR_NLD]) {
-#pragma unroll
-    for (int i = 0; i < FR_NLD; ++i) {
-        const int e = tid + 256 * i;
-        if (e < NF * 16) store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[i]);
-    }
-}
-// rows 97..111 of the image feed only accumulator rows that are dropped, but must hold finite numbers
-__device__ __forceinline__ void frame_zero_pad(_Float16* ahi, _Float16* alo, int tid) {
-    for (int e = tid; e < (FR_RP - NF) * 16; e += 256)
-        store_split4<FR_RP>(ahi, alo, NF + (e >> 4), (e & 15) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 // Per-head LayerNorm + split-precision store, one wave per head (N values held flat, index i = f*D + e = the

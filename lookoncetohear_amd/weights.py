@@ -167,14 +167,17 @@ def pack_all(sd: dict, n_blocks: int, prefix: str = "tfgridnet.") -> dict:
     g = lambda k: sd[prefix + k].detach()
     out = {
         "wfb_t": pack_mfma_f32(g("enc.filterbank._filters")[:, 0].t()),      # [192 samples, 194 rows] -> [13][48][64]
-        "wfb_dec": pack_mfma_f32(g("dec.filterbank._filters")[:, 0], k_pad=208),   # [194 -> 208, 192] -> [12][52][64]
+        # synthesis filterbank as a split-precision B image: W[n = sample][k = spectrum row], 194 rows padded to 224
+        "wfb_dec": pack_linear_f16x3(torch.nn.functional.pad(g("dec.filterbank._filters")[:, 0].t(), (0, 224 - 194))),   # [12][7][64][2][8]
         "conv_w": pack_mfma_f32(g("conv.0.weight").reshape(-1, 36).t()),     # [36 taps (ch,kt,kf), 64] -> [4][9][64]
         "conv_b": g("conv.0.bias"),
         "emb_w": g("embed_to_feats_proj.0.weight"), "emb_b": g("embed_to_feats_proj.0.bias"),
         "emb_ln_w": g("embed_to_feats_proj.1.weight"), "emb_ln_b": g("embed_to_feats_proj.1.bias"),
-        "deconv_w": pack_mfma_f32(g("deconv.weight").permute(0, 2, 3, 1).reshape(-1, 36)),   # [64, (kt,kf,o)] -> [3][16][64]
+        # transposed-conv taps as a split-precision B image: W[n = (kt,kf,o)][k = c], 36 columns padded to 48
+        "deconv_w": pack_linear_f16x3(torch.nn.functional.pad(g("deconv.weight").permute(0, 2, 3, 1).reshape(-1, 36).t(),
+                                                              (0, 0, 0, 12))),   # [3][2][64][2][8]
         "deconv_b": g("deconv.bias"),
     }
-    out = {k: v.contiguous().float() for k, v in out.items()}
+    out = {k: (v.contiguous() if v.dtype == torch.float16 else v.contiguous().float()) for k, v in out.items()}
     out["blocks"] = [pack_block(sd, f"{prefix}blocks.{i}.") for i in range(n_blocks)]
     return out
