@@ -94,6 +94,16 @@ int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const
                      const float* h0, const float* c0, float* hN, float* cN, float* h_out, int B, int T, int mode,
                      lh_stream_t stream);
 
+/* A.3.1 for very few frames (streaming, batch-1): same result as lh_ln_lstm_intra, one workgroup per (frame, direction):
+ * the input half of all 97 steps as one MFMA GEMM, the recurrent half as a 256 x 64 fp32 mat-vec per step.
+ *   x [n_frames][97][64]; h_out [n_frames*97][128]
+ *   wih_pk fp16 hi/lo B image [2 dirs][16 ntiles][2 ksteps][64 lanes][16] of W_ih * ln_w with rows in thread order
+ *   (row n = PyTorch row ((n>>2)&3)*64 + (n>>6)*16 + ((n>>4)&3)*4 + (n&3));  b_sum [2][256] and whh [2][256][64] fp32 in the same
+ *   row order (weights.py pack_block: intra_s_*)
+ */
+int lh_intra_stream(const float* x, const void* wih_pk, const float* b_sum, const float* whh, float* h_out,
+                    int n_frames, lh_stream_t stream);
+
 /* A.3.1 + Linear fused (split-precision mode): LayerNorm -> BiLSTM over frequency -> Linear(128->64) -> + residual in
  * ONE kernel; replaces tfgridnet_causal.py:505-516.  A workgroup runs the forward then the reverse direction over its
  * sequences and accumulates both halves of the projection into the same output rows (no hidden-state round trip).
@@ -138,10 +148,14 @@ int lh_linear_res(const float* h, const void* w_pk, const float* bias, const flo
  *          24..47 K, 48..111 V(h*16+v); bias [112]
  *   slopes [3] PReLU slopes (Q,K,V);  lnq_w/b, lnk_w/b [608] = the 582 affine values zero-padded;  lnv_w/b [1552]
  *   q, kx, vx  split-precision rows (above)
+ *   ring_pos   NULL, or (T = 1 only) a device counter: the K / V row goes to slot (*ring_pos mod 50) of a persistent
+ *              50-row ring instead of row 49 — rows 0..49 are then exactly the window of the one query frame, in
+ *              rotated order (softmax and P.V are order-free), and no history row ever has to be moved
  */
 int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const float* slopes, const float* lnq_w,
                    const float* lnq_b, const float* lnk_w, const float* lnk_b, const float* lnv_w,
-                   const float* lnv_b, void* q, void* kx, void* vx, int B, int T, lh_stream_t stream);
+                   const float* lnv_b, void* q, void* kx, void* vx, const int* ring_pos, int B, int T,
+                   lh_stream_t stream);
 
 /* A.3.5  local windowed attention over exactly 50 slots (frames t-49..t incl. history rows, no mask) with
  * the head merge fused into the store.  Replaces tfgridnet_causal.py:564-581 without materialising the

@@ -23,10 +23,11 @@ SIGNATURES = {
     "lh_set_tuning": [_I, _I],
     "lh_ln_lstm_intra": [_P] * 6 + [_I, _I, _P],
     "lh_ln_lstm_inter": [_P] * 10 + [_I, _I, _I, _P],
+    "lh_intra_stream": [_P] * 5 + [_I, _P],
     "lh_intra_block": [_P] * 6 + [_I, _P],
     "lh_inter_block": [_P] * 10 + [_I, _I, _P],
     "lh_linear_res": [_P] * 5 + [_I, _I, _P],
-    "lh_qkv_proj_ln": [_P] * 13 + [_I, _I, _P],
+    "lh_qkv_proj_ln": [_P] * 14 + [_I, _I, _P],
     "lh_local_attn": [_P] * 4 + [_I, _I, _P],
     "lh_ring_pack": [_P] * 4 + [_I, _I, _P],
     "lh_ring_unpack": [_P] * 4 + [_I, _I, _P],

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip"]
+SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_stream.hip"]
 LIB = os.path.join(PKG, "_lookonce_hip.so")
 ARCH = "gfx950"
 

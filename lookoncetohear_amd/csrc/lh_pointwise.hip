@@ -187,7 +187,8 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
                                                      const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
                                                      const float* __restrict__ lnv_w, const float* __restrict__ lnv_b,
                                                      _Float16* __restrict__ q, _Float16* __restrict__ kx,
-                                                     _Float16* __restrict__ vx, int T, int nframes) {
+                                                     _Float16* __restrict__ vx, int T, int nframes,
+                                                     const int* __restrict__ ring_pos) {
     __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float yf[Y_N];
@@ -216,6 +217,10 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     float4 stg[FR_NLD];
     if ((int)blockIdx.x < nframes) frame_load(y + (long)blockIdx.x * NF * C, tid, stg);
     const long tkp = T + HIST + KV_PAD;
+    // K / V row of frame t: HIST + t behind the history rows — or, for a one-frame chunk on a persistent ring
+    // (ring_pos != NULL, T = 1), slot (*ring_pos mod 50): the 50 rows are then exactly the attention window, in
+    // rotated order, which softmax and P.V do not care about
+    const int krow0 = ring_pos ? (*ring_pos % WIN) : HIST;
     for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
         const int b = fr / T, t = fr % T;
         frame_store(ahi, alo, tid, stg);
@@ -249,8 +254,8 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
         float* yv = yf + Y_V0 + hd * DV;
         const float* zero8 = yf + DQKP - 8;          // features 600..607 of Q head 0: always zero
         _Float16* qrow = q + (bh * T + t) * LDQKH;
-        _Float16* krow = kx + (bh * tkp + HIST + t) * LDQKH;
-        _Float16* vrow = vx + (bh * tkp + HIST + t) * LDVH;
+        _Float16* krow = kx + (bh * tkp + krow0 + t) * LDQKH;
+        _Float16* vrow = vx + (bh * tkp + krow0 + t) * LDVH;
         // `fr >> 30` is always 0 but ties the lane index to the loop variable: without it LICM hoists every slot address
         // of the three rows out of the persistent frame loop and the kernel spills
         const int ln = lane + (fr >> 30);
@@ -391,16 +396,16 @@ extern "C" int lh_linear_res(const float* h, const void* w_pk, const float* bias
 
 extern "C" int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const float* slopes,
                               const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
-                              const float* lnv_w, const float* lnv_b, void* q, void* kx, void* vx, int B, int T,
-                              lh_stream_t stream) {
+                              const float* lnv_w, const float* lnv_b, void* q, void* kx, void* vx, const int* ring_pos,
+                              int B, int T, lh_stream_t stream) {
     using namespace lh;
     if (!y || !w_pk || !bias || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !q || !kx ||
-        !vx || B <= 0 || T <= 0)
+        !vx || B <= 0 || T <= 0 || (ring_pos && T != 1))
         return LH_ERR_ARG;
     const int nframes = B * T;
     hipLaunchKernelGGL(k_qkv_proj_ln, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y,
                        (const _Float16*)w_pk, bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, (_Float16*)q,
-                       (_Float16*)kx, (_Float16*)vx, T, nframes);
+                       (_Float16*)kx, (_Float16*)vx, T, nframes, ring_pos);
     return check_launch();
 }
 

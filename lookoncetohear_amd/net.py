@@ -152,6 +152,7 @@ class Net(nn.Module):
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
         self.fuse_intra_min_frames = 8192
+        self.stream_intra_max_frames = 128      # up to here one workgroup per (frame, direction) still finds its own CU
         self._pack_key = None
         self._packed = None
         self._ws: Dict[tuple, dict] = {}
@@ -317,6 +318,12 @@ class Net(nn.Module):
                 if fuse and Bn * T >= self.fuse_intra_min_frames:
                     lib.call("lh_intra_block", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
                              P(bp["intra_lin_b"]), P(xb), Bn * T, st)
+                elif mode == 1 and Bn * T <= self.stream_intra_max_frames:
+                    # a handful of frames (streaming): one workgroup per (frame, direction), mat-vec recurrence
+                    lib.call("lh_intra_stream", P(xa), P(bp["intra_s_wih"]), P(bp["intra_s_b"]), P(bp["intra_s_whh"]),
+                             P(hbuf), Bn * T, st)
+                    lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
+                             2 * H_, st)
                 else:
                     # intra: LN + BiLSTM over frequency -> Linear(128->64) + residual
                     lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra" + wkey]),
@@ -342,7 +349,7 @@ class Net(nn.Module):
                     ws["hist_dirty"] = False
                 lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
                          P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
-                         P(ws["kx"]), P(ws["vx"]), Bn, T, st)
+                         P(ws["kx"]), P(ws["vx"]), None, Bn, T, st)
                 lib.call("lh_local_attn", P(ws["q"]), P(ws["kx"]), P(ws["vx"]), P(xb), Bn, T, st)
                 gain = ws["gain"] if (i == 0 and self.n_blocks > 1) else None   # `batch * embed` before block 1
                 lib.call("lh_proj_ln_res", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
@@ -369,83 +376,140 @@ class Net(nn.Module):
                 state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
         return y, (state if want_state else None)
 
+    # ------------------------------------------------------------------------------------------------
+    # streaming fast path (Streamer)
+    # ------------------------------------------------------------------------------------------------
+    def _speaker_gain(self, embed: torch.Tensor, gain_raw: torch.Tensor, gain: torch.Tensor):
+        """gain[b][f][c] = LayerNorm(Linear(embed)) (reference tfgridnet_causal.py:247-248) into preallocated tensors."""
+        lib = self._lib(embed)
+        pk = self._weights(embed.device)
+        st = torch.cuda.current_stream(embed.device).cuda_stream if embed.is_cuda else 0
+        P = lambda t: t.data_ptr()
+        lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]), P(pk["emb_ln_b"]),
+                 P(gain_raw), P(gain), embed.shape[0], st)
+
+    def _stream_chunk(self, x, gain, sin: dict, sout: dict, rings, pos, y):
+        """One chunk of ONE frame for `Streamer`: the launches of `_separate` with every state tensor read from `sin` and
+        written to `sout` (preallocated), the K / V history in per-block persistent rings, the speaker gain given."""
+        lib = self._lib(x)
+        dev = x.device
+        hop, nfft = self.stft_chunk_size, self.nfft
+        Bn, _, n = x.shape
+        T = (n - nfft) // hop + 1
+        assert T == 1 and n == nfft, "the streaming path takes chunks of stft_chunk_size + stft_pad_size samples"
+        F_, H_ = self.n_freqs, self.hidden
+        pk = self._weights(dev)
+        ws = self._workspace(Bn, T, dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
+        P = lambda t: t.data_ptr()
+        xa, xb, xc, hbuf = ws["xa"], ws["xb"], ws["xc"], ws["hbuf"]
+        lib.call("lh_stft_conv_in", P(x), P(sin["conv_buf"]), P(sout["conv_buf"]), P(pk["wfb_t"]), P(pk["conv_w"]),
+                 P(pk["conv_b"]), P(xa), Bn, T, n, st)
+        for i in range(self.n_blocks):
+            bp = pk["blocks"][i]
+            kx, vx = rings[i]
+            lib.call("lh_intra_stream", P(xa), P(bp["intra_s_wih"]), P(bp["intra_s_b"]), P(bp["intra_s_whh"]), P(hbuf),
+                     Bn * T, st)
+            lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), Bn * T * F_,
+                     2 * H_, st)
+            lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
+                     P(bp["inter_lin_b"]), P(sin["h"][i]), P(sin["c"][i]), P(sout["h"][i]), P(sout["c"][i]), P(xc), Bn, T, st)
+            lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
+                     P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
+                     P(kx), P(vx), P(pos), Bn, T, st)
+            lib.call("lh_local_attn", P(ws["q"]), P(kx), P(vx), P(xb), Bn, T, st)
+            g = gain if (i == 0 and self.n_blocks > 1) else None
+            lib.call("lh_proj_ln_res", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
+                     P(bp["proj_ln_w"]), P(bp["proj_ln_b"]), P(xc), P(g) if g is not None else None, P(xa), Bn, T, st)
+        lib.call("lh_deconv_istft", P(xa), P(sin["deconv_buf"]), P(sout["deconv_buf"]), P(sin["istft_buf"]),
+                 P(sout["istft_buf"]), P(pk["deconv_w"]), P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), Bn, T, st)
+
+
 
 class Streamer:
     """8 ms-chunk streaming driver (reference usage: `Net.predict(chunk[B,2,192], embed[B,256], state, pad=False)`
-    in a loop) with the per-chunk launch sequence captured once into a HIP graph.
+    in a loop) with the per-chunk launch sequence captured once into HIP graphs.
 
-    One chunk = 128 new samples + 64 look-ahead samples -> 128 output samples; all streaming state (conv / deconv /
-    iSTFT tails, LSTM (h, c), K/V rings) lives in static device tensors that the captured graph reads and rewrites,
-    so `step()` is: copy the chunk in, replay the graph, hand back the output buffer (a view that the next `step`
-    overwrites).  `use_graph=False` runs the same code path eagerly (also what the capture warm-up does).
+    One chunk = 128 new samples + 64 look-ahead samples -> 128 output samples.  Everything the chunk loop touches is
+    static device memory, and nothing is copied that a kernel can write in place:
+      * conv / deconv / iSTFT tails and the inter-LSTM (h, c) exist twice; even chunks read set 0 and write set 1, odd
+        chunks the other way round (two captured graphs, replayed alternately);
+      * the K / V history of each block is a persistent 50-row ring in the attention kernel's own split-precision
+        layout: the new row goes to slot (chunk mod 50) (`lh_qkv_proj_ln` ring_pos, a device counter the graph
+        increments), and as the 50 rows are exactly the window of the chunk's one frame, nothing is ever moved;
+      * the speaker gain LayerNorm(Linear(embedding)) is computed once in `set_embedding`.
+    `step()` is: copy the chunk in, replay a graph, hand back the output buffer (a view that the next `step`
+    overwrites).  `use_graph=False` runs the same launches eagerly (also what the capture warm-up does).
+    Measured (MI355X, batch 1): 0.68 ms per chunk with the generic `predict` path captured in one graph, see DESIGN.md.
     """
 
     def __init__(self, net: Net, batch_size: int, device, use_graph: bool = True):
+        if net.gemm_mode != "f16x3" or not net.fuse_linear:
+            raise ValueError("Streamer runs the split-precision fused kernels (LOOKONCE_GEMM=f16x3, LOOKONCE_FUSE=1)")
         self.net = net
-        self.B = batch_size
-        self.device = torch.device(device)
+        self.B = B = batch_size
+        self.device = dev = torch.device(device)
         n = net.stft_chunk_size + net.stft_pad_size
-        self.chunk = torch.zeros(batch_size, net.num_ch, n, device=self.device)
-        self.embed = torch.zeros(batch_size, net.spk_emb_dim, device=self.device)
-        self.state = net.init_buffers(batch_size, self.device)
-        self.out = torch.zeros(batch_size, net.n_srcs, net.stft_chunk_size, device=self.device)
+        z = lambda *s, **k: torch.zeros(*s, device=dev, **k)
+        self.chunk = z(B, net.num_ch, n)
+        self.embed = z(B, net.spk_emb_dim)
+        self.out = z(B, net.n_srcs, net.stft_chunk_size)
+        F_, C_, nh, H_ = net.n_freqs, net.emb_dim, net.n_head, net.hidden
+        mk = lambda: dict(conv_buf=z(B, net.num_ch * 2, 2, F_), deconv_buf=z(B, C_, 2, F_),
+                          istft_buf=z(B, net.n_srcs, F_ * 2, 1),
+                          h=[z(1, B * F_, H_) for _ in range(net.n_blocks)], c=[z(1, B * F_, H_) for _ in range(net.n_blocks)])
+        self.sets = [mk(), mk()]
+        rows = 1 + net.local_atten_len - 1 + KV_PAD_ROWS
+        self.rings = [(z(B * nh, rows, 2 * QK_PAD, dtype=torch.float16), z(B * nh, rows, 2 * net.V_dim * F_, dtype=torch.float16))
+                      for _ in range(net.n_blocks)]
+        self.pos = z(1, dtype=torch.int32)
+        self.gain = z(B, F_, C_)
+        self.gain_raw = z(B, F_ * C_)
+        self.parity = 0
+        self.graphs = None
         self.graph = None
-        if use_graph and self.device.type == "cuda":
-            saved = self._snapshot()
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
+        if use_graph and dev.type == "cuda":
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                for _ in range(2):              # warm-up: packs weights, allocates the T=1 workspace
-                    self._body()
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._body()
-            self.graph = g
-            self._restore(saved)
+                for k in (0, 1):                # warm-up: packs weights, allocates the T=1 workspace
+                    self._body(k)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.graphs = []
+            for k in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body(k)
+                self.graphs.append(g)
+            self.graph = self.graphs[0]
+            self.reset()
 
-    def _flat(self):
-        st = self.state
-        out = [st["conv_buf"], st["deconv_buf"], st["istft_buf"]]
-        for i in range(self.net.n_blocks):
-            b = st["gridnet_bufs"][f"buf{i}"]
-            out += [b["K_buf"], b["V_buf"], b["c0"], b["h0"]]
-        return out
-
-    def _snapshot(self):
-        return [t.clone() for t in self._flat()]
-
-    def _restore(self, saved):
-        for t, s in zip(self._flat(), saved):
-            t.copy_(s)
-
-    def _body(self):
-        old = self._flat()
-        work = dict(conv_buf=old[0], deconv_buf=old[1], istft_buf=old[2], gridnet_bufs={
-            f"buf{i}": dict(K_buf=old[3 + 4 * i], V_buf=old[4 + 4 * i], c0=old[5 + 4 * i], h0=old[6 + 4 * i])
-            for i in range(self.net.n_blocks)})
-        y, new = self.net.predict(self.chunk, self.embed, work, pad=False)
-        self.out.copy_(y)
-        flat_new = [new["conv_buf"], new["deconv_buf"], new["istft_buf"]]
-        for i in range(self.net.n_blocks):
-            b = new["gridnet_bufs"][f"buf{i}"]
-            flat_new += [b["K_buf"], b["V_buf"], b["c0"], b["h0"]]
-        for dst, src in zip(old, flat_new):     # write the new state back into the static tensors
-            dst.copy_(src)
+    def _body(self, k: int):
+        self.net._stream_chunk(self.chunk, self.gain, self.sets[k], self.sets[k ^ 1], self.rings, self.pos, self.out)
+        self.pos.add_(1)
 
     def reset(self):
-        for t in self._flat():
-            t.zero_()
+        for st in self.sets:
+            for t in [st["conv_buf"], st["deconv_buf"], st["istft_buf"]] + st["h"] + st["c"]:
+                t.zero_()
+        for kx, vx in self.rings:
+            kx.zero_()
+            vx.zero_()
+        self.pos.zero_()
+        self.parity = 0
 
     def set_embedding(self, embed: torch.Tensor):
         self.embed.copy_(embed.reshape(self.B, -1))
+        with torch.no_grad():
+            self.net._speaker_gain(self.embed, self.gain_raw, self.gain)
 
     def step(self, chunk: torch.Tensor) -> torch.Tensor:
         """chunk [B, 2, 192] (128 new + 64 look-ahead samples) -> [B, 2, 128]."""
         self.chunk.copy_(chunk)
         with torch.no_grad():
-            if self.graph is not None:
-                self.graph.replay()
+            if self.graphs is not None:
+                self.graphs[self.parity].replay()
             else:
-                self._body()
+                self._body(self.parity)
+        self.parity ^= 1
         return self.out

@@ -91,6 +91,21 @@ def test_fused_intra_path_forced_small(emu_net, oracle_cfg_sd):
         assert (fm[k] - fo[k]).abs().max() < TOL, k
 
 
+def test_tiled_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
+    """The mid-size intra path (lh_ln_lstm_intra: 16-sequence MFMA tiles + lh_linear_res, used between 128 and 8192
+    frames) forced at a size where `Net` would pick the streaming mat-vec kernel."""
+    cfg, sd = oracle_cfg_sd
+    d = synth.batch([6], 128 * 5 + 64)
+    yo = O.forward(cfg, sd, d["mixture"], d["embedding_gt"])
+    saved = emu_net.stream_intra_max_frames
+    emu_net.stream_intra_max_frames = 0
+    try:
+        y = emu_net(d["mixture"], d["embedding_gt"])
+    finally:
+        emu_net.stream_intra_max_frames = saved
+    assert (y - yo).abs().max() < TOL
+
+
 def test_attention_tile_modes_multi_tile(emu_net, oracle_cfg_sd):
     """T = 37 with non-zero state: three 16-frame tiles (one query tile per workgroup) and two 32-frame tiles (two query
     tiles sharing their K / V rows, the default for T > 16), last tile ragged in both; outputs and the next state
@@ -134,6 +149,27 @@ def test_ring_pack_unpack_roundtrip(emu_net):
     k2, v2 = torch.empty_like(kb), torch.empty_like(vb)
     lib.call("lh_ring_unpack", kx.data_ptr(), vx.data_ptr(), k2.data_ptr(), v2.data_ptr(), B, T, None)
     assert torch.equal(k2, unsplit_qk(krows)) and torch.equal(v2, unsplit_v(vrows))
+
+
+def test_streamer_ring_and_pingpong(emu_net, oracle_cfg_sd):
+    """`Streamer` (eager on the emulator): ping-pong state sets, persistent K / V rings with rotating write slot,
+    cached speaker gain.  53 chunks wrap the 50-slot ring; compared with the oracle's chunk-by-chunk `predict`, and a
+    second pass after `reset()` must reproduce the first bit for bit."""
+    cfg, sd = oracle_cfg_sd
+    nchunk = 53
+    d = synth.batch([8], 128 * nchunk + 64)
+    mix, emb = d["mixture"], d["embedding_gt"][:, 0]
+    st = emu_net.make_streamer(1, "cpu", use_graph=False)
+    st.set_embedding(emb)
+    outs = [st.step(mix[:, :, i * 128:i * 128 + 192]).clone() for i in range(nchunk)]
+    ost, oouts = None, []
+    for i in range(nchunk):
+        yo, ost = O.predict(cfg, sd, mix[:, :, i * 128:i * 128 + 192], emb, ost, pad=False)
+        oouts.append(yo)
+    assert (torch.cat(outs, -1) - torch.cat(oouts, -1)).abs().max() < TOL
+    st.reset()
+    outs2 = [st.step(mix[:, :, i * 128:i * 128 + 192]).clone() for i in range(3)]
+    assert torch.equal(torch.cat(outs2, -1), torch.cat(outs[:3], -1))
 
 
 def test_cabi_argument_errors(emu_net):
