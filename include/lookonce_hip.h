@@ -97,9 +97,10 @@ int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const
 /* A.3.1 for very few frames (streaming, batch-1): same result as lh_ln_lstm_intra, one workgroup per (frame, direction):
  * the input half of all 97 steps as one MFMA GEMM, the recurrent half as a 256 x 64 fp32 mat-vec per step.
  *   x [n_frames][97][64]; h_out [n_frames*97][128]
- *   wih_pk fp16 hi/lo B image [2 dirs][16 ntiles][2 ksteps][64 lanes][16] of W_ih * ln_w with rows in thread order
- *   (row n = PyTorch row ((n>>2)&3)*64 + (n>>6)*16 + ((n>>4)&3)*4 + (n&3));  b_sum [2][256] and whh [2][256][64] fp32 in the same
- *   row order (weights.py pack_block: intra_s_*)
+ *   wih_pk fp16 hi/lo B image [2 dirs][16 ntiles][2 ksteps][64 lanes][16] of W_ih * ln_w with the gate columns in the
+ *   kernel's order (column n = PyTorch row (n&3)*64 + (n>>5)*8 + ((n>>3)&3)*2 + ((n>>2)&1));  b_sum [2][256] in the
+ *   same order;  whh [2][512][32] fp32 = the same rows of W_hh cut into their two k halves (weights.py pack_block:
+ *   intra_s_*)
  */
 int lh_intra_stream(const float* x, const void* wih_pk, const float* b_sum, const float* whh, float* h_out,
                     int n_frames, lh_stream_t stream);

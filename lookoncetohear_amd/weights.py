@@ -122,14 +122,15 @@ def pack_block(sd: dict, pre: str) -> dict:
                g("intra_rnn.bias_hh_l0_reverse"))])
     out["inter_w16"] = pack_lstm_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["inter_b16"] = fold_b(g("inter_rnn.weight_ih_l0"), eb, g("inter_rnn.bias_ih_l0"), g("inter_rnn.bias_hh_l0"))
-    # streaming intra kernel (lh_stream.hip): rows permuted into thread order — thread n = 64 w + 16 r + 4 g + l owns
-    # gate g of hidden unit 16 w + 4 r + l, i.e. PyTorch row g*64 + 16 w + 4 r + l
+    # streaming intra kernel (lh_stream.hip): gate columns in the order n = 32 w + 8 r + 4 u + g  <->  gate g of hidden
+    # unit 8 w + 2 r + u (PyTorch row g*64 + unit); W_hh additionally split into the two k halves of thread 2n + kh
     n = torch.arange(256, device=iw.device)
-    perm = ((n >> 2) & 3) * 64 + (n >> 6) * 16 + ((n >> 4) & 3) * 4 + (n & 3)
+    perm = (n & 3) * 64 + (n >> 5) * 8 + ((n >> 3) & 3) * 2 + ((n >> 2) & 1)
     out["intra_s_wih"] = torch.stack([pack_linear_f16x3(fold_w(g("intra_rnn.weight_ih_l0"), iw)[perm]),
                                       pack_linear_f16x3(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw)[perm])])
     out["intra_s_b"] = out["intra_b16"][:, perm]
-    out["intra_s_whh"] = torch.stack([g("intra_rnn.weight_hh_l0")[perm], g("intra_rnn.weight_hh_l0_reverse")[perm]])
+    out["intra_s_whh"] = torch.stack([g("intra_rnn.weight_hh_l0")[perm].reshape(512, 32),
+                                      g("intra_rnn.weight_hh_l0_reverse")[perm].reshape(512, 32)])
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
     out["intra_lin_w"], out["intra_lin_b"] = pack_linear_f16x3(g("intra_linear.weight")), g("intra_linear.bias")
