@@ -160,6 +160,9 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
     //      [hi 4 | lo 4] quad of a V row per key); the head merge is fused into the store
     {
         const int b = bh / NH, hd = bh % NH;
+        // gridDim.y workgroups share one (batch, head, tile): each recomputes the (cheap) scores and takes every
+        // gridDim.y-th round of column groups — a chunk of ONE frame would otherwise keep 4 of the 256 CUs busy
+        const int part = blockIdx.y, nsplit = gridDim.y;
         // key row of (step ks, slot j) for this lane: 32 ks + 8 g4 + j; rows >= NKEYS are never needed (P = 0 there)
         const int lrow = g4 * 8 * LDVH;
         auto qcol = [&](int cg) { return min(min(cg, AT_CG - 1) * 16 + l15, DV / 4 - 1) * 8; };   // quad offset in halves
@@ -181,14 +184,14 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
             }
         };
 #pragma unroll
-        for (int s = 0; s < RING - 1; ++s) fill(s % RING, s % AT_PKS, qcol(wave + 4 * (s / AT_PKS)));
+        for (int s = 0; s < RING - 1; ++s) fill(s % RING, s % AT_PKS, qcol(wave + 4 * (part + nsplit * (s / AT_PKS))));
         f32x4 am[MQ][4], ac[MQ][4];
         // fully unrolled (7 column groups for wave 0, 6 for the others): exact vmcnt waits instead of a drain of the
         // ring at every loop back-edge
         constexpr int NSTEP = ((AT_CG + 3) / 4) * AT_PKS;
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            const int ks = s % AT_PKS, cg = wave + 4 * (s / AT_PKS);
+            const int ks = s % AT_PKS, cg = wave + 4 * (part + nsplit * (s / AT_PKS));
             if (cg >= AT_CG) break;                    // wave-uniform
             if (ks == 0) {
 #pragma unroll
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
                     }
             }
             {
-                const int sn = s + RING - 1, cgn = wave + 4 * (sn / AT_PKS);
+                const int sn = s + RING - 1, cgn = wave + 4 * (part + nsplit * (sn / AT_PKS));
                 if (cgn < AT_CG) fill(sn % RING, sn % AT_PKS, qcol(cgn));
             }
             // regroup: column tile c takes element c of the 8 key rows -> one f16x8 B operand (hi and lo)
@@ -336,7 +339,8 @@ extern "C" int lh_local_attn(const void* q, const void* kx, const void* vx, floa
     // The two-tile kernel runs a two-deep V ring: with three slots it needs more than 256 registers.
     const int mq = T <= 16 ? 1 : g_attn_mq;
     const int ntt = (T + 16 * mq - 1) / (16 * mq);
-    const dim3 grid(bh8 * ntt);
+    // latency-bound launches (a handful of workgroups): split the V columns of a tile over 7 workgroups
+    const dim3 grid(bh8 * ntt, bh8 * ntt <= 64 ? 7 : 1);
     const _Float16 *qh = (const _Float16*)q, *kh = (const _Float16*)kx, *vh = (const _Float16*)vx;
     if (mq == 1)
         hipLaunchKernelGGL((k_local_attn<1, 3>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
