@@ -44,6 +44,9 @@ KERNEL_WORK = {
     # fused kernels: LSTM + output projection + residual (two launches per block for the bidirectional intra path)
     "lh_intra_block": dict(flops=625 * 97 * 2 * (2 * 128 * 256 + 128 * 64), bytes=5 * 15.52e6, bound="mfma"),
     "lh_inter_block": dict(flops=625 * 97 * 2 * (128 * 256 + 64 * 64), bytes=2 * 15.52e6, bound="mfma"),
+    # small-batch / streaming variants: same algorithmic work as the kernels they stand in for
+    "lh_inter_matvec": dict(flops=625 * 97 * 2 * (128 * 256 + 64 * 64), bytes=2 * 15.52e6, bound="mfma"),
+    "lh_intra_stream": dict(flops=625 * 97 * 2 * 2 * 128 * 256, bytes=(1 + 2) * 15.52e6, bound="mfma"),
     "lh_linear_res": dict(flops=625 * 97 * 2 * 96 * 64, bytes=(1.5 + 1 + 1) * 15.52e6, bound="hbm"),   # avg K=96
     "lh_qkv_proj_ln": dict(flops=625 * 97 * 2 * 64 * 112, bytes=15.52e6 + 2 * 5.82e6 + 15.52e6, bound="hbm"),
     "lh_local_attn": dict(flops=4 * 625 * 50 * 2 * (582 + 1552), bytes=2 * 5.82e6 + 2 * 15.52e6, bound="hbm"),
@@ -57,7 +60,8 @@ KERNEL_WORK = {
 # kernel launches behind one C-ABI call (HIP events bracket the call; rocprofv3 reports per kernel launch)
 LAUNCHES_PER_CALL = {"lh_intra_block": 2, "lh_embed_proj_ln": 2, "lh_metric_sums": 2}
 # the kernel function behind each call, as rocprofv3 names it (profiles/*kernel_stats*.csv)
-KERNEL_NAME = {"lh_intra_block": "k_ln_lstm_lin<1> (intra grid)", "lh_inter_block": "k_ln_lstm_lin<1> (inter grid)",
+KERNEL_NAME = {"lh_inter_matvec": "k_inter_matvec", "lh_intra_stream": "k_intra_stream",
+               "lh_intra_block": "k_ln_lstm_lin<1> (intra grid)", "lh_inter_block": "k_ln_lstm_lin<1> (inter grid)",
                "lh_local_attn": "k_local_attn", "lh_qkv_proj_ln": "k_qkv_proj_ln", "lh_proj_ln_res": "k_proj_ln_res",
                "lh_deconv_istft": "k_deconv_istft", "lh_stft_conv_in": "k_stft_conv_in"}
 

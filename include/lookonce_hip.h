@@ -105,6 +105,16 @@ int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const
 int lh_intra_stream(const float* x, const void* wih_pk, const float* b_sum, const float* whh, float* h_out,
                     int n_frames, lh_stream_t stream);
 
+/* A.3.2 + Linear fused for few sequences (batch <= 5): same result as lh_inter_block, one workgroup per sequence
+ * (b, f), 64-step chunks: input half and output projection as MFMA GEMMs around a mat-vec recurrence.
+ *   x, out [B][T][97][64] (must not alias); h0, c0, hN, cN [B*97][64]
+ *   wih_pk [16 ntiles][2 ksteps][64 lanes][16], b_sum [256], whh [512][32]: the lh_intra_stream layouts for the inter
+ *   LSTM (weights.py pack_block: inter_s_*);  wlin_pk [4][2][64][16], blin [64] as lh_inter_block
+ */
+int lh_inter_matvec(const float* x, const void* wih_pk, const float* b_sum, const float* whh, const void* wlin_pk,
+                    const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,
+                    lh_stream_t stream);
+
 /* A.3.1 + Linear fused (split-precision mode): LayerNorm -> BiLSTM over frequency -> Linear(128->64) -> + residual in
  * ONE kernel; replaces tfgridnet_causal.py:505-516.  A workgroup runs the forward then the reverse direction over its
  * sequences and accumulates both halves of the projection into the same output rows (no hidden-state round trip).

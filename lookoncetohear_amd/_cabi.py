@@ -24,6 +24,7 @@ SIGNATURES = {
     "lh_ln_lstm_intra": [_P] * 6 + [_I, _I, _P],
     "lh_ln_lstm_inter": [_P] * 10 + [_I, _I, _I, _P],
     "lh_intra_stream": [_P] * 5 + [_I, _P],
+    "lh_inter_matvec": [_P] * 11 + [_I, _I, _P],
     "lh_intra_block": [_P] * 6 + [_I, _P],
     "lh_inter_block": [_P] * 10 + [_I, _I, _P],
     "lh_linear_res": [_P] * 5 + [_I, _I, _P],

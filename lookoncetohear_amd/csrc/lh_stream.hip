@@ -120,6 +120,137 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Inter-frame LSTM for few sequences (batch 1-5 offline): LayerNorm -> causal LSTM over time with carried (h, c) ->
+// Linear(64->64) -> + residual  (tfgridnet_causal.py:521-538), one workgroup per sequence (b, f).
+// The tiled kernel (k_ln_lstm_lin) needs 16 sequences per workgroup: at batch 1 that is 7 workgroups walking 625
+// steps at ~1.1 us each (0.7 ms per block, 2.1 of the 3.0 ms forward).  Here every sequence gets its own CU and the
+// step is the same 256 x 64 mat-vec as in k_intra_stream; the time axis is cut into chunks of 64 steps whose input
+// half (LN(x) W_ih'^T + b) and output projection (h W_lin^T + b + residual) run as split-precision MFMA GEMMs before
+// and after the chunk's recurrence.
+// ------------------------------------------------------------------------------------------------------
+constexpr int IM_TC = 64;                  // steps per chunk
+constexpr int IM_A = 2 * 4 * IM_TC * 8;    // halves per [64 x 64] A image
+constexpr int IM_XP = C + 4;               // raw-x staging row
+
+__global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict__ x, const _Float16* __restrict__ wih_pk,
+                                                        const float* __restrict__ b_sum, const float* __restrict__ whh,
+                                                        const _Float16* __restrict__ wlin_pk, const float* __restrict__ blin,
+                                                        const float* __restrict__ h0, const float* __restrict__ c0,
+                                                        float* __restrict__ hN, float* __restrict__ cN,
+                                                        float* __restrict__ out, int T) {
+    __shared__ __attribute__((aligned(16))) _Float16 xhi[IM_A];          // LN(x) of the chunk's steps
+    __shared__ __attribute__((aligned(16))) _Float16 xlo[IM_A];
+    __shared__ __attribute__((aligned(16))) _Float16 hhi[IM_A];          // h_t of the chunk's steps
+    __shared__ __attribute__((aligned(16))) _Float16 hlo[IM_A];
+    __shared__ __attribute__((aligned(16))) float xraw[IM_TC * IM_XP];   // un-normalised rows (residual)
+    __shared__ __attribute__((aligned(16))) float gxs[IM_TC * IS_GP];    // input half of the gates, [step][column]
+    __shared__ __attribute__((aligned(16))) float hs[2][H];              // h_{t-1} / h_t
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int seq = blockIdx.x, b = seq / NF, f = seq % NF;              // state row b*97 + f
+    const float* xs = x + ((long)b * T * NF + f) * C;                    // step t -> + t * 97 * 64
+    float* os = out + ((long)b * T * NF + f) * C;
+    const long tstride = (long)NF * C;
+
+    const int kh = tid & 1;
+    float wr[H / 2];
+    {
+        const float* wp = whh + (long)tid * (H / 2);
+#pragma unroll
+        for (int k4 = 0; k4 < H / 8; ++k4) {
+            const float4 v = *reinterpret_cast<const float4*>(wp + k4 * 4);
+            wr[k4 * 4 + 0] = v.x; wr[k4 * 4 + 1] = v.y; wr[k4 * 4 + 2] = v.z; wr[k4 * 4 + 3] = v.w;
+        }
+    }
+    const int unit = wave * 8 + g4 * 2 + (l15 >> 3);
+    const bool cell_lane = (l15 & 7) == 0;
+    float c = cell_lane ? c0[(long)seq * H + unit] : 0.f;
+    if (tid < H) hs[0][tid] = h0[(long)seq * H + tid];
+    int hb = 0;                                                          // hs buffer holding h_{t-1}
+
+    for (int t0 = 0; t0 < T; t0 += IM_TC) {
+        const int nst = min(IM_TC, T - t0);
+        // ---- stage the chunk: raw rows (residual) and LayerNorm'ed rows as the x A image; 16 threads per row
+#pragma unroll
+        for (int i = 0; i < IM_TC * 16 / IS_NT; ++i) {
+            const int e = tid + IS_NT * i, r = e >> 4, q4 = (e & 15) * 4;
+            float4 v = *reinterpret_cast<const float4*>(&xs[(long)min(t0 + r, T - 1) * tstride + q4]);
+            *reinterpret_cast<float4*>(&xraw[r * IM_XP + q4]) = v;
+            const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+            v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+            const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+            const float rstd = rsqrtf(var + LN_EPS);
+            store_split4<IM_TC>(xhi, xlo, r, q4, make_float4(v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd));
+        }
+        __syncthreads();
+        // ---- G_x[step][n] = b[n] + LN(x)[step] . W_ih'[n]: wave w owns column tiles 2w, 2w+1
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            const int nt = 2 * wave + i;
+            f16x8 wh[2], wl[2];
+            load_w<2>(wih_pk, nt, lane, wh, wl);
+            const float bz = b_sum[nt * 16 + l15];
+#pragma unroll 1
+            for (int m = 0; m < IM_TC / 16; ++m) {
+                const f32x4 acc = mma_tile<IM_TC, 2>(xhi, xlo, m, g4, l15, wh, wl, bz);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gxs[(m * 16 + g4 * 4 + r) * IS_GP + nt * 16 + l15] = acc[r];
+            }
+        }
+        __syncthreads();
+        // ---- recurrence over the chunk's steps (see k_intra_stream); h_t also goes into the projection's A image
+        for (int it = 0; it < nst; ++it) {
+            const float* hp = hs[hb] + kh * (H / 2);
+            float a0 = kh ? 0.f : gxs[it * IS_GP + (tid >> 1)], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float4 hreg[H / 8];
+#pragma unroll
+            for (int k4 = 0; k4 < H / 8; ++k4) hreg[k4] = *reinterpret_cast<const float4*>(hp + k4 * 4);
+#if defined(__AMDGCN__)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int k4 = 0; k4 < H / 8; ++k4) {
+                a0 = fmaf(wr[k4 * 4 + 0], hreg[k4].x, a0);
+                a1 = fmaf(wr[k4 * 4 + 1], hreg[k4].y, a1);
+                a2 = fmaf(wr[k4 * 4 + 2], hreg[k4].z, a2);
+                a3 = fmaf(wr[k4 * 4 + 3], hreg[k4].w, a3);
+            }
+            const float part = (a0 + a1) + (a2 + a3);
+            const float gate = part + row_ror_mov<15>(part);
+            const float gf = row_ror_mov<14>(gate), gg = row_ror_mov<12>(gate), go = row_ror_mov<10>(gate);
+            if (cell_lane) {
+                float hv;
+                lstm_cell(gate, gf, gg, go, c, hv);
+                hs[hb ^ 1][unit] = hv;
+                const _Float16 hh = (_Float16)hv;
+                const int idx = a_index<IM_TC>(it, unit);
+                hhi[idx] = hh;
+                hlo[idx] = (_Float16)((hv - (float)hh) * PW_SPLIT);
+            }
+            hb ^= 1;
+            __syncthreads();
+        }
+        // ---- projection + residual: out[step][o] = x[step][o] + b[o] + sum_u h[step][u] W_lin[o][u]; 16 (row tile,
+        //      column tile) products over the 8 waves
+#pragma unroll 1
+        for (int p = wave; p < (IM_TC / 16) * 4; p += 8) {
+            const int mt = p >> 2, nt = p & 3;
+            f16x8 wh[2], wl[2];
+            load_w<2>(wlin_pk, nt, lane, wh, wl);
+            const f32x4 acc = mma_tile<IM_TC, 2>(hhi, hlo, mt, g4, l15, wh, wl, blin[nt * 16 + l15]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int st = mt * 16 + g4 * 4 + r;
+                if (st < nst) os[(long)(t0 + st) * tstride + nt * 16 + l15] = acc[r] + xraw[st * IM_XP + nt * 16 + l15];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < H) hN[(long)seq * H + tid] = hs[hb][tid];
+    if (cell_lane) cN[(long)seq * H + unit] = c;
+}
+
 }  // namespace lh
 
 extern "C" int lh_intra_stream(const float* x, const void* wih_pk, const float* b_sum, const float* whh, float* h_out,
@@ -128,5 +259,17 @@ extern "C" int lh_intra_stream(const float* x, const void* wih_pk, const float* 
     if (!x || !wih_pk || !b_sum || !whh || !h_out || n_frames <= 0) return LH_ERR_ARG;
     hipLaunchKernelGGL(k_intra_stream, dim3(2 * n_frames), dim3(IS_NT), 0, (hipStream_t)stream, x, (const _Float16*)wih_pk,
                        b_sum, whh, h_out, n_frames);
+    return check_launch();
+}
+
+extern "C" int lh_inter_matvec(const float* x, const void* wih_pk, const float* b_sum, const float* whh, const void* wlin_pk,
+                               const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out,
+                               int B, int T, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !wih_pk || !b_sum || !whh || !wlin_pk || !blin || !h0 || !c0 || !hN || !cN || !out || B <= 0 || T <= 0)
+        return LH_ERR_ARG;
+    if (h0 == hN || c0 == cN || x == out) return LH_ERR_ARG;
+    hipLaunchKernelGGL(k_inter_matvec, dim3(B * NF), dim3(IS_NT), 0, (hipStream_t)stream, x, (const _Float16*)wih_pk, b_sum,
+                       whh, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, T);
     return check_launch();
 }

@@ -152,6 +152,7 @@ class Net(nn.Module):
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
         self.fuse_intra_min_frames = 8192
+        self.inter_matvec_max_seqs = 512        # inter LSTM: per-sequence workgroups up to two rounds of CUs (batch <= 5)
         self.stream_intra_max_frames = 128      # up to here one workgroup per (frame, direction) still finds its own CU
         self._pack_key = None
         self._packed = None
@@ -330,7 +331,11 @@ class Net(nn.Module):
                              P(bp["intra" + bkey]), P(hbuf), Bn * T, mode, st)
                     lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), rows,
                              2 * H_, st)
-                if fuse:
+                if fuse and Bn * F_ <= self.inter_matvec_max_seqs and T >= 32:
+                    # few sequences, many steps (batch 1 offline): one workgroup per sequence, mat-vec recurrence
+                    lib.call("lh_inter_matvec", P(xb), P(bp["inter_s_wih"]), P(bp["inter_s_b"]), P(bp["inter_s_whh"]),
+                             P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
+                elif fuse:
                     lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
                              P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
                 else:

@@ -131,6 +131,10 @@ def pack_block(sd: dict, pre: str) -> dict:
     out["intra_s_b"] = out["intra_b16"][:, perm]
     out["intra_s_whh"] = torch.stack([g("intra_rnn.weight_hh_l0")[perm].reshape(512, 32),
                                       g("intra_rnn.weight_hh_l0_reverse")[perm].reshape(512, 32)])
+    # the same layout for the per-sequence inter kernel (lh_inter_matvec, small batches)
+    out["inter_s_wih"] = pack_linear_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew)[perm])
+    out["inter_s_b"] = out["inter_b16"][perm]
+    out["inter_s_whh"] = g("inter_rnn.weight_hh_l0")[perm].reshape(512, 32)
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
     out["intra_lin_w"], out["intra_lin_b"] = pack_linear_f16x3(g("intra_linear.weight")), g("intra_linear.bias")

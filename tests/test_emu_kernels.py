@@ -106,6 +106,28 @@ def test_tiled_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     assert (y - yo).abs().max() < TOL
 
 
+def test_inter_matvec_two_chunks(emu_net, oracle_cfg_sd):
+    """Per-sequence inter LSTM (lh_inter_matvec, batch <= 5 and T >= 32): T = 70 = one full 64-step chunk + a ragged one,
+    carried (h, c) in and out, against the oracle; the tiled kernel (lh_inter_block) on the same input must agree."""
+    cfg, sd = oracle_cfg_sd
+    B, T = 1, 70
+    d = synth.batch([9], 128 * T + 64)
+    st = O.random_state(cfg, B, 11)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    assert (y - yo).abs().max() < TOL
+    fo, fm = O.flat_state(so), O.flat_state(s2)
+    for k in fo:
+        assert (fm[k] - fo[k]).abs().max() < TOL, k
+    saved = emu_net.inter_matvec_max_seqs
+    emu_net.inter_matvec_max_seqs = 0
+    try:
+        y2, _ = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    finally:
+        emu_net.inter_matvec_max_seqs = saved
+    assert (y2 - y).abs().max() < 2e-5
+
+
 def test_attention_tile_modes_multi_tile(emu_net, oracle_cfg_sd):
     """T = 37 with non-zero state: three 16-frame tiles (one query tile per workgroup) and two 32-frame tiles (two query
     tiles sharing their K / V rows, the default for T > 16), last tile ragged in both; outputs and the next state
