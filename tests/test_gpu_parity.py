@@ -147,6 +147,22 @@ def test_graph_streamer_matches_eager(net, golden):
     assert torch.equal(ys, torch.cat(outs2, -1))
 
 
+def test_graph_streamer_batch3_matches_predict_loop(net):
+    """Batch-3 `Streamer` (ping-pong state, rotating K/V ring slots, 60 chunks = more than one turn of the 50-slot
+    ring) against the eager `Net.predict` loop that carries the reference-shaped fp32 state through lh_ring_pack/unpack."""
+    nchunk, B = 60, 3
+    d = synth.batch([11, 12, 13], 128 * nchunk + 64)
+    mix, emb = d["mixture"].to(DEV), d["embedding_gt"][:, 0].to(DEV)
+    st = net.make_streamer(B, DEV, use_graph=True)
+    st.set_embedding(emb)
+    ys = torch.cat([st.step(mix[:, :, i * 128:i * 128 + 192]).clone() for i in range(nchunk)], -1)
+    state, outs = net.init_buffers(B, DEV), []
+    for i in range(nchunk):
+        y, state = net.predict(mix[:, :, i * 128:i * 128 + 192], emb, state, pad=False)
+        outs.append(y)
+    assert _err(ys, torch.cat(outs, -1).cpu()) < TOL
+
+
 def test_metric_kernels_match_torch_definition(net):
     from lookoncetohear_amd.metrics import metric_sums, metric_sums_device, per_utterance
     d = synth.batch([11, 12, 13], 80000)
