@@ -78,34 +78,41 @@ __device__ __forceinline__ double si_snr_from_moments(double sp, double st, doub
     return 10.0 * log10((sig + eps) / (fmax(noise, 0.0) + eps));
 }
 
-// one workgroup: per-utterance rows [B][3] = (output_sisnr, si_snr_i, embedding_sim) and sums[4] (fp64)
+// one workgroup: per-utterance rows [B][3] = (output_sisnr, si_snr_i, embedding_sim) and sums[4] (fp64).
+// One wave per utterance: lanes 0..15 add up the 16 chunk partials of their (channel, moment), all 64 lanes share the
+// cosine similarity (a single thread per utterance walked 256 + 256 dependent fp64 loads: 42 us per call).
 __global__ void __launch_bounds__(256) k_metric_finish(const double* __restrict__ part, const float* __restrict__ emb,
                                                        const float* __restrict__ emb_gt, float* __restrict__ rows,
                                                        double* __restrict__ sums, int B, int n, int edim) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* rows64 = const_cast<double*>(part) + (long)B * 2 * MT_CHUNKS * MT_NM;     // [B][3] tail of the scratch
-    for (int b = tid; b < B; b += 256) {
+    for (int b = wave; b < B; b += 4) {
+        double m = 0.0;                                       // lane = ch * 8 + k (< 16): moment k of channel ch
+        if (lane < 2 * MT_NM)
+            for (int c = 0; c < MT_CHUNKS; ++c) m += part[(((long)b * 2 + (lane >> 3)) * MT_CHUNKS + c) * MT_NM + (lane & 7)];
         double out_sisnr = 0.0, snr_i = 0.0;
         for (int ch = 0; ch < 2; ++ch) {
-            double m[MT_NM];
-            for (int k = 0; k < MT_NM; ++k) m[k] = 0.0;
-            for (int c = 0; c < MT_CHUNKS; ++c)
-                for (int k = 0; k < MT_NM; ++k) m[k] += part[(((long)b * 2 + ch) * MT_CHUNKS + c) * MT_NM + k];
-            const double so = si_snr_from_moments(m[0], m[1], m[3], m[4], m[6], (double)n);
-            const double sm = si_snr_from_moments(m[2], m[1], m[5], m[4], m[7], (double)n);
+            double mm[MT_NM];
+#pragma unroll
+            for (int k = 0; k < MT_NM; ++k) mm[k] = __shfl(m, ch * MT_NM + k);
+            const double so = si_snr_from_moments(mm[0], mm[1], mm[3], mm[4], mm[6], (double)n);
+            const double sm = si_snr_from_moments(mm[2], mm[1], mm[5], mm[4], mm[7], (double)n);
             out_sisnr += 0.5 * so;
             snr_i += 0.5 * (so - sm);
         }
         double ab = 0.0, aa = 0.0, bb = 0.0;
-        for (int i = 0; i < edim; ++i) {
+        for (int i = lane; i < edim; i += 64) {
             const double x = emb[(long)b * edim + i], yv = emb_gt[(long)b * edim + i];
             ab += x * yv; aa += x * x; bb += yv * yv;
         }
+        ab = wave_sum_f64(ab); aa = wave_sum_f64(aa); bb = wave_sum_f64(bb);
         const double cosv = ab / (fmax(sqrt(aa), 1e-8) * fmax(sqrt(bb), 1e-8));     // F.cosine_similarity, eps 1e-8
-        rows[b * 3 + 0] = (float)out_sisnr;
-        rows[b * 3 + 1] = (float)snr_i;
-        rows[b * 3 + 2] = (float)cosv;
-        rows64[b * 3 + 0] = snr_i; rows64[b * 3 + 1] = out_sisnr; rows64[b * 3 + 2] = cosv;
+        if (lane == 0) {
+            rows[b * 3 + 0] = (float)out_sisnr;
+            rows[b * 3 + 1] = (float)snr_i;
+            rows[b * 3 + 2] = (float)cosv;
+            rows64[b * 3 + 0] = snr_i; rows64[b * 3 + 1] = out_sisnr; rows64[b * 3 + 2] = cosv;
+        }
     }
     __syncthreads();
     if (tid == 0) {                                           // sequential: bit-reproducible sums
