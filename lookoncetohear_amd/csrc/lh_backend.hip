@@ -32,12 +32,16 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                                                         float* __restrict__ ibuf_out, const _Float16* __restrict__ wd_pk,
                                                         const float* __restrict__ bd, const _Float16* __restrict__ wfb_pk,
                                                         float* __restrict__ wave_out, int B, int T) {
-    __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];                     // A image of one input frame
-    __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
-    __shared__ float pring[3][NF][BE_PP];                                           // partial products of 3 frames
+    // Two input frames per loop iteration (half the barriers; at one frame the loop was ~80 % stall): two A images, and
+    // a partial-product ring of 4 frames (2 being written while the gather still reads the 2 before them).
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * FR_A];                 // A images of two input frames
+    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * FR_A];
+    __shared__ float pring[4][NF][BE_PP];                                           // partial products of 4 frames
     __shared__ __attribute__((aligned(16))) _Float16 sxh[NSRC * BE_SA];             // A image of the 16 spectra
     __shared__ __attribute__((aligned(16))) _Float16 sxl[NSRC * BE_SA];
-    __shared__ __attribute__((aligned(16))) float frs[BE_NJ][NSRC][BE_FP];          // synthesis frames
+    // synthesis frames: only live after the frame loop, in the space of the (then dead) hi A images
+    static_assert(sizeof(float) * BE_NJ * NSRC * BE_FP <= sizeof(_Float16) * 2 * FR_A, "frs must fit in ahi");
+    float (*frs)[NSRC][BE_FP] = reinterpret_cast<float (*)[NSRC][BE_FP]>(ahi);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
     // B fragments: the deconv taps [64 -> 48 columns] (3 column tiles x 2 k-steps, 6 KB) sit in LDS in fragment order;
@@ -53,7 +57,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
 
     // rows / k-padding of the A images that are never written only feed dropped outputs or multiply zero weights,
     // but must be finite
-    for (int i = tid; i < FR_A; i += BE_NT) { ahi[i] = (_Float16)0.f; alo[i] = (_Float16)0.f; }
+    for (int i = tid; i < 2 * FR_A; i += BE_NT) { ahi[i] = (_Float16)0.f; alo[i] = (_Float16)0.f; }
     for (int i = tid; i < NSRC * BE_SA; i += BE_NT) { sxh[i] = (_Float16)0.f; sxl[i] = (_Float16)0.f; }
 
     const int tiles_per_b = (T + BE_TT - 1) / BE_TT;
@@ -97,29 +101,34 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             if (fr_first + u < fr_end) load_frame(fr_first + u, stg[u]);
         for (int fbase = fr_first; fbase < fr_end; fbase += BE_RING) {
 #pragma unroll
-          for (int u = 0; u < BE_RING; ++u) {
-            const int fr = fbase + u;
+          for (int u = 0; u < BE_RING; u += 2) {
+            const int fr = fbase + u;                 // this iteration: frames fr and fr + 1 (the second may not exist)
             if (fr >= fr_end) break;
-            // stage frame fr into the A image, refill its ring slot
+            const bool two = fr + 1 < fr_end;
+            // stage the frames into the two A images, refill their ring slots
 #pragma unroll
             for (int i = 0; i < BE_NLD; ++i) {
                 const int e = tid + BE_NT * i;
-                if (e < NF * 16) store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[u][i]);
+                if (e < NF * 16) {
+                    store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[u][i]);
+                    if (two) store_split4<FR_RP>(ahi + FR_A, alo + FR_A, e >> 4, (e & 15) * 4, stg[u + 1][i]);
+                }
             }
             __syncthreads();
             if (fr + BE_RING < fr_end) load_frame(fr + BE_RING, stg[u]);
+            if (fr + 1 + BE_RING < fr_end) load_frame(fr + 1 + BE_RING, stg[u + 1]);
 
-            // P[fr] = Y[fr] (97 x 64) * Wd (64 x 48): 21 (row tile, column tile) products over the 8 waves
-            const int slot = ((fr % 3) + 3) % 3;
-            for (int p = wave; p < 21; p += 8) {
-                const int mt = p / 3, nt = p % 3;
+            // P[fr + q] = Y[fr + q] (97 x 64) * Wd (64 x 48): 2 x 21 (row tile, column tile) products over the 8 waves
+            for (int p = wave; p < (two ? 42 : 21); p += 8) {
+                const int q = p >= 21, pp = p - 21 * q, mt = pp / 3, nt = pp % 3;
+                const int slot = (fr + q + 4) & 3;    // fr >= -2
                 f16x8 wh[2], wl[2];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     wh[ks] = *reinterpret_cast<const f16x8*>(&wds[((nt * 2 + ks) * 64 + lane) * 16]);
                     wl[ks] = *reinterpret_cast<const f16x8*>(&wds[((nt * 2 + ks) * 64 + lane) * 16 + 8]);
                 }
-                const f32x4 acc = mma_tile<FR_RP, 2>(ahi, alo, mt, g4, l15, wh, wl, 0.f);
+                const f32x4 acc = mma_tile<FR_RP, 2>(ahi + q * FR_A, alo + q * FR_A, mt, g4, l15, wh, wl, 0.f);
                 const int col = nt * 16 + l15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -129,30 +138,30 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             }
             __syncthreads();
 
-            // output frame td = fr: D[o][f] = b[o] + sum_{kt,kf} P[td-kt][f+1-kf][(kt*3+kf)*4 + o]
-            const int td = fr;
-            if (td >= t0 - 1 && td >= 0) {
+            // output frames td = fr, fr + 1: D[o][f] = b[o] + sum_{kt,kf} P[td-kt][f+1-kf][(kt*3+kf)*4 + o]
+            for (int i = tid; i < (two ? 2 : 1) * 4 * NF; i += BE_NT) {
+                const int q = i >= 4 * NF, ii = i - 4 * NF * q;
+                const int td = fr + q;
+                if (td < t0 - 1 || td < 0) continue;
                 const int jd = td + 1 - t0;           // Sx frame index inside the tile
-                for (int i = tid; i < 4 * NF; i += BE_NT) {
-                    const int o = i & 3, f = i >> 2;
-                    float v = bias4[o];
+                const int o = ii & 3, f = ii >> 2;
+                float v = bias4[o];
 #pragma unroll
-                    for (int kt = 0; kt < 3; ++kt) {
-                        const int pf = td - kt;
-                        if (pf < -2) continue;
-                        const int ps = ((pf % 3) + 3) % 3;
+                for (int kt = 0; kt < 3; ++kt) {
+                    const int pf = td - kt;
+                    if (pf < -2) continue;
+                    const int ps = (pf + 4) & 3;
 #pragma unroll
-                        for (int kf = 0; kf < 3; ++kf) {
-                            const int fi = f + 1 - kf;
-                            if (fi >= 0 && fi < NF) v += pring[ps][fi][(kt * 3 + kf) * 4 + o];
-                        }
+                    for (int kf = 0; kf < 3; ++kf) {
+                        const int fi = f + 1 - kf;
+                        if (fi >= 0 && fi < NF) v += pring[ps][fi][(kt * 3 + kf) * 4 + o];
                     }
-                    const int s = o >> 1, k = (o & 1) * NF + f;
-                    put_sx(jd, s, k, v);
-                    if (td == T - 1) ibuf_out[((long)b * NSRC + s) * NK + k] = v;      // new carried spectrum (exact fp32)
                 }
+                const int s = o >> 1, k = (o & 1) * NF + f;
+                put_sx(jd, s, k, v);
+                if (td == T - 1) ibuf_out[((long)b * NSRC + s) * NK + k] = v;      // new carried spectrum (exact fp32)
             }
-            // the next iteration's staging barrier orders these pring reads before the slot is overwritten 3 frames later
+            // the next iteration's staging barrier orders these pring reads before their slots are overwritten
           }
         }
         __syncthreads();
@@ -192,6 +201,9 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             if (n < NFFT - HOP) v += frs[jt][s][n + HOP];
             wave_out[((long)b * NSRC + s) * L + (long)(t0 + jt) * HOP + n] = v;
         }
+        __syncthreads();
+        // frs lived in the hi A images: their pad rows (97..111 feed dropped outputs) must hold finite numbers again
+        for (int i = tid; i < 2 * FR_A; i += BE_NT) ahi[i] = (_Float16)0.f;
     }
 }
 
