@@ -15,6 +15,7 @@
 //     112-128, which keeps 2-3 workgroups resident per CU for latency hiding;
 //   * LayerNorm / PReLU / residual epilogues run out of LDS with compile-time index algebra.
 #include "lh_split.h"
+#include <type_traits>
 
 namespace lh {
 
@@ -227,23 +228,26 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
         __syncthreads();                      // image complete; also orders the previous frame's reads of `yf`
         if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
-#pragma unroll 1
-        for (int m = 0; m < FR_RP / 16; ++m) {
+        // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check
+        auto row_tile = [&](int m, auto checked) {
             const f32x4 r0 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh0, wl0, bz0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m * 16 + g4 * 4 + r;
-                if (row < NF) yf[base0 + row * str0] = prelu_f(r0[r], a0);
+                if (!checked.value || row < NF) yf[base0 + row * str0] = prelu_f(r0[r], a0);
             }
             if (two) {
                 const f32x4 r1 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh1, wl1, bz1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m * 16 + g4 * 4 + r;
-                    if (row < NF) yf[base1 + row * VD] = prelu_f(r1[r], sv);
+                    if (!checked.value || row < NF) yf[base1 + row * VD] = prelu_f(r1[r], sv);
                 }
             }
-        }
+        };
+#pragma unroll 1
+        for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{});
+        row_tile(NF / 16, std::true_type{});
         __syncthreads();
 
         // per-head LayerNorm: wave w normalises head w of Q, K and V and writes the split-precision rows
@@ -328,15 +332,18 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
         for (int k = 0; k < NSLOT; ++k)
             rv[k] = *reinterpret_cast<const float4*>(&y2[fr + (long)min(tid + 256 * k, N4 - 1) * 4]);
 
-#pragma unroll 1
-        for (int m = 0; m < FR_RP / 16; ++m) {
+        // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check
+        auto row_tile = [&](int m, auto checked) {
             const f32x4 acc = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh, wl, bz);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m * 16 + g4 * 4 + r;
-                if (row < NF) ys[row * YP + wave * 16 + l15] = prelu_f(acc[r], a);
+                if (!checked.value || row < NF) ys[row * YP + wave * 16 + l15] = prelu_f(acc[r], a);
             }
-        }
+        };
+#pragma unroll 1
+        for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{});
+        row_tile(NF / 16, std::true_type{});
         __syncthreads();
 
         // joint LayerNorm over all 97*64 values of the frame (flat index f*64 + c), float4 granules
