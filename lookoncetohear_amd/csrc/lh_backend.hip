@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     // a partial-product ring of 4 frames (2 being written while the gather still reads the 2 before them).
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * FR_A];                 // A images of two input frames
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * FR_A];
-    __shared__ float pring[4][NF][BE_PP];                                           // partial products of 4 frames
+    // partial products of 4 frames; bin f sits in row f + 1, rows 0 and 98 stay zero (the f -/+ 1 taps of the edge bins)
+    __shared__ float pring[4][NF + 2][BE_PP];
     __shared__ __attribute__((aligned(16))) _Float16 sxh[NSRC * BE_SA];             // A image of the 16 spectra
     __shared__ __attribute__((aligned(16))) _Float16 sxl[NSRC * BE_SA];
     // synthesis frames: only live after the frame loop, in the space of the (then dead) hi A images
@@ -59,6 +60,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     // but must be finite
     for (int i = tid; i < 2 * FR_A; i += BE_NT) { ahi[i] = (_Float16)0.f; alo[i] = (_Float16)0.f; }
     for (int i = tid; i < NSRC * BE_SA; i += BE_NT) { sxh[i] = (_Float16)0.f; sxl[i] = (_Float16)0.f; }
+    for (int i = tid; i < 4 * 2 * BE_PP; i += BE_NT) pring[i / (2 * BE_PP)][((i / BE_PP) & 1) * (NF + 1)][i % BE_PP] = 0.f;
 
     const int tiles_per_b = (T + BE_TT - 1) / BE_TT;
     const long L = (long)HOP * T;
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = mt * 16 + g4 * 4 + r;
-                    if (f < NF && col < BE_NP) pring[slot][f][col] = acc[r];
+                    if (f < NF && col < BE_NP) pring[slot][f + 1][col] = acc[r];
                 }
             }
             __syncthreads();
@@ -148,14 +150,9 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                 float v = bias4[o];
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
-                    const int pf = td - kt;
-                    if (pf < -2) continue;
-                    const int ps = (pf + 4) & 3;
+                    const int ps = (td - kt + 4) & 3;         // td >= 0, so frame td - kt >= -2 exists (halo or zero state)
 #pragma unroll
-                    for (int kf = 0; kf < 3; ++kf) {
-                        const int fi = f + 1 - kf;
-                        if (fi >= 0 && fi < NF) v += pring[ps][fi][(kt * 3 + kf) * 4 + o];
-                    }
+                    for (int kf = 0; kf < 3; ++kf) v += pring[ps][f + 2 - kf][(kt * 3 + kf) * 4 + o];   // guard rows: no bounds
                 }
                 const int s = o >> 1, k = (o & 1) * NF + f;
                 put_sx(jd, s, k, v);
