@@ -161,6 +161,7 @@ class Net(nn.Module):
         self._lib_override = None          # TEST HOOK ONLY (tests/hipemu): never set on the product path
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: list of (kernel tag, start event, end event) per launch
+        self._prof_only: Optional[set] = None
 
     # ------------------------------------------------------------------------------------------------
     # reference API
@@ -280,11 +281,12 @@ class Net(nn.Module):
             taps = self._debug_taps
             xa, xb, xc, hbuf = ws["xa"], ws["xb"], ws["xc"], ws["hbuf"]
             prof = self._prof if x.is_cuda else None
+            only = self._prof_only                   # bench.py: restrict the event pairs to these C-ABI calls
 
             class _Timed:                       # HIP events on the launch stream around each C-ABI call
                 @staticmethod
                 def call(name, *args):
-                    if prof is None:
+                    if prof is None or (only is not None and name not in only):
                         return lib_.call(name, *args)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
