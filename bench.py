@@ -421,6 +421,9 @@ def main():
         roof["launches_per_call"] = lpc            # achieved = work of one call / duration of one call (= per launch too)
         roof["avg_call_ms"] = kern[dom]["avg_ms"]
         roof["avg_launch_ms"] = kern[dom]["avg_ms"] / lpc
+        # the same call in the fully instrumented warm-up step (event pairs around every call, as rocprofv3's tracer
+        # also separates the dispatches): the figure to hold against profiles/*kernel_stats*.csv
+        roof["avg_launch_ms_instrumented_step"] = breakdown[dom]["avg_ms"] / lpc
         roof["share_of_gpu_time"] = kern[dom]["avg_ms"] * breakdown[dom]["launches"] / gpu_ms
         out = {
             "metric": "frames_per_sec (5 s 16 kHz binaural clips, 625 STFT frames each, offline forward)",
