@@ -144,11 +144,10 @@ def bench_embed(args, dev, rank, world, dist):
     A step = one forward of the batch; utterances shard across ranks with no exchange at all (embeddings stay local)."""
     from lookoncetohear_amd import synth
     from lookoncetohear_amd.embed_net import EmbedTFGridNet
-    from oracle import embedder_oracle as E
+    from lookoncetohear_amd import config
     B = 64 if args.batch == 32 else args.batch
-    cfg = E.ECfg(**E.EMBED_PARAMS)
-    net = EmbedTFGridNet(**E.EMBED_PARAMS).eval()
-    net.load_state_dict(E.synthetic_state_dict(cfg, 0), strict=True)
+    net = EmbedTFGridNet(**config.EMBED_PARAMS).eval()
+    net.load_state_dict(config.embedder_weights(0), strict=True)
     net = net.to(dev)
     uniq = min(B, 8)
     x = synth.batch([rank * B + i for i in range(uniq)], 80000)["mixture"]
@@ -181,7 +180,7 @@ def bench_embed(args, dev, rank, world, dist):
     if rank != 0:
         return
     # algorithmic fp32-equivalent FLOPs of the dominant candidates, per clip (T = 1251 frames, 65 bins)
-    nblk = cfg.nblk
+    nblk = config.EMBED_PARAMS["num_blocks"]
     work = {
         "lh_emb_attn_block": 2.0 * T * 65 * 64 * (128 + 64) + 4 * (2.0 * T * T * 520 + 2.0 * T * T * 1040),
         "lh_emb_axis.intra": 2.0 * T * 62 * (256 * 512 + 128 * 512) + 2.0 * T * 65 * 512 * 64,
@@ -197,8 +196,9 @@ def bench_embed(args, dev, rank, world, dist):
     if not args.no_cpu_baseline:
         t1 = time.perf_counter()
         torch.set_num_threads(min(32, os.cpu_count() or 1))
+        from oracle import embedder_oracle as E      # cpu_baseline leg only
         xs = x[:1, :, :16000].cpu()
-        E.forward(cfg, E.synthetic_state_dict(cfg, 0), xs)
+        E.forward(E.ECfg(**E.EMBED_PARAMS), E.synthetic_state_dict(E.ECfg(**E.EMBED_PARAMS), 0), xs)
         dt = time.perf_counter() - t1
         cpu = {"value": 251 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": "oracle/embedder_oracle.py (torch CPU fp32), 1 x 1 s clip = 251 frames, one pass"}
@@ -317,12 +317,11 @@ def main():
         return bench_render(args, dev, rank, world, dist)
     from lookoncetohear_amd.net import Net
     from lookoncetohear_amd.metrics import metric_sums_device
-    from oracle import tfgridnet_oracle as O
+    from lookoncetohear_amd import config
     _cabi.load()                                                    # fail loudly if the HIP extension is missing
 
-    cfg = O.Cfg(**O.TSH_PARAMS)
-    net = Net(**O.TSH_PARAMS).eval()
-    net.load_state_dict(O.synthetic_state_dict(cfg, 0), strict=True)    # random-init weights of the tsh.json arch
+    net = Net(**config.TSH_PARAMS).eval()
+    net.load_state_dict(config.separator_weights(0), strict=True)   # random-init weights of the tsh.json arch
     net = net.to(dev)
     if args.gemm:
         net.gemm_mode = args.gemm

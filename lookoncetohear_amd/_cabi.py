@@ -75,6 +75,15 @@ class Lib:
         return getattr(self._dll, name)
 
 
+def device_of(t):
+    """Context manager: make `t`'s GPU the current HIP device around raw C-ABI launches (they go to the CURRENT device,
+    and the reference eval driver builds `cuda:N` tensors without torch.cuda.set_device, src/ts_hear_test.py:175).
+    No-op for host tensors (only the emulator test hook passes those)."""
+    import contextlib
+    import torch
+    return torch.cuda.device(t.device) if t.is_cuda else contextlib.nullcontext()
+
+
 _hip_lib = None
 
 

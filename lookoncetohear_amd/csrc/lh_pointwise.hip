@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     // K / V row of frame t: HIST + t behind the history rows — or, for a one-frame chunk on a persistent ring
     // (ring_pos != NULL, T = 1), slot (*ring_pos mod 50): the 50 rows are then exactly the attention window, in
     // rotated order, which softmax and P.V do not care about
-    const int krow0 = ring_pos ? (*ring_pos % WIN) : HIST;
+    const int krow0 = ring_pos ? (int)((unsigned)*ring_pos % (unsigned)WIN) : HIST;   // unsigned: never before the ring
     for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
         const int b = fr / T, t = fr % T;
         frame_store(ahi, alo, tid, stg);

@@ -109,7 +109,10 @@ class EmbedTFGridNet(nn.Module):
             raise ValueError(f"enrollment of {N} samples is too short: needs > {self.n_fft // 2} samples (reflect padding) "
                              f"and >= {self.emb_ks} STFT frames (unfold kernel), like the reference")
         F_, C_ = self.n_freqs, 64
-        with torch.no_grad():
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("lookoncetohear_amd.EmbedTFGridNet is an inference-only drop-in (no autograd): call .eval() "
+                               "and/or run under torch.no_grad()")
+        with torch.no_grad(), _cabi.device_of(x):
             pk = self._weights(dev)
             st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
             P = lambda t: t.data_ptr()

@@ -53,6 +53,7 @@ def metric_sums_device(outputs, mixture, target, embedding, embedding_gt, lib=No
     rows = torch.empty(B, 3, dtype=torch.float32, device=dev)
     sums = torch.empty(4, dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream if outputs.is_cuda else 0
-    lib.call("lh_metric_sums", o.data_ptr(), t.data_ptr(), m.data_ptr(), e.data_ptr(), g.data_ptr(), scratch.data_ptr(),
-             rows.data_ptr(), sums.data_ptr(), B, n, e.shape[1], st)
+    with _cabi.device_of(o):
+        lib.call("lh_metric_sums", o.data_ptr(), t.data_ptr(), m.data_ptr(), e.data_ptr(), g.data_ptr(),
+                 scratch.data_ptr(), rows.data_ptr(), sums.data_ptr(), B, n, e.shape[1], st)
     return sums, rows

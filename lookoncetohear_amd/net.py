@@ -44,18 +44,21 @@ def mod_pad(x: torch.Tensor, chunk_size: int, pad: Tuple[int, int]):
     return x, mod
 
 
+_device_of = _cabi.device_of
+
+
 def stft_filterbank(n_fft: int, hop: int) -> torch.Tensor:
     """Analysis/synthesis filterbank buffer `[n_fft + 2, 1, n_fft]` (asteroid-filterbanks STFTFB as called at
     reference tfgridnet_causal.py:131-135): sqrt-periodic-Hann windowed real-DFT rows, 97 cosine rows then 97
     negative-sine rows, DC/Nyquist cosine rows scaled by 1/sqrt(2), overall 1/(0.5*sqrt(n_fft^2/hop))."""
     nbin = n_fft // 2 + 1
-    n = np.arange(n_fft, dtype=np.float64)
-    window = np.sqrt(0.5 * (1.0 - np.cos(2.0 * np.pi * n / n_fft)))
-    ang = 2.0 * np.pi * np.outer(np.arange(nbin), n) / n_fft
-    rows = np.concatenate([np.cos(ang), -np.sin(ang)], axis=0)
-    rows[0] *= 1.0 / np.sqrt(2.0)
-    rows[n_fft // 2] *= 1.0 / np.sqrt(2.0)
-    rows *= window[None, :] / (0.5 * np.sqrt(n_fft * n_fft / hop))
+    n = np.arange(n_fft)
+    window = np.sqrt(0.5 - 0.5 * np.cos(2 * np.pi * n / n_fft))
+    ang = 2 * np.pi * np.arange(nbin)[:, None] * n[None, :] / n_fft
+    re, im = np.cos(ang), -np.sin(ang)
+    re[0] /= np.sqrt(2)
+    re[n_fft // 2] /= np.sqrt(2)
+    rows = np.vstack([re, im]) * window[None, :] / (0.5 * np.sqrt(n_fft * n_fft / hop))
     return torch.from_numpy(rows).float().unsqueeze(1)
 
 
@@ -162,6 +165,15 @@ class Net(nn.Module):
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: list of (kernel tag, start event, end event) per launch
         self._prof_only: Optional[set] = None
+        # asteroid-filterbanks' STFTFB may register a second buffer (`torch_window`) next to `_filters` (un-vendored,
+        # version unpinned: could not be checked here).  The kernels only need `_filters`, so such keys of a reference
+        # checkpoint are dropped before the strict key check instead of failing it.
+        self._register_load_state_dict_pre_hook(self._drop_foreign_filterbank_keys)
+
+    @staticmethod
+    def _drop_foreign_filterbank_keys(state_dict, prefix, *_):
+        for k in [k for k in state_dict if k.startswith(prefix) and ".filterbank." in k and not k.endswith("._filters")]:
+            state_dict.pop(k)
 
     # ------------------------------------------------------------------------------------------------
     # reference API
@@ -255,6 +267,9 @@ class Net(nn.Module):
 
     def _separate(self, x: torch.Tensor, embed: torch.Tensor, state: Optional[dict], want_state: bool = True):
         """TFGridNet.forward (reference tfgridnet_causal.py:188-283) on the HIP kernels."""
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("lookoncetohear_amd.Net is an inference-only drop-in (forward kernels, no autograd): call "
+                               ".eval() and/or run under torch.no_grad(); training stays on the reference model")
         lib = self._lib(x)
         dev = x.device
         hop, nfft = self.stft_chunk_size, self.nfft
@@ -271,7 +286,9 @@ class Net(nn.Module):
         embed = embed.contiguous().float()
         F_, C_, nh, H_ = self.n_freqs, self.emb_dim, self.n_head, self.hidden
         hist = self.local_atten_len - 1
-        with torch.no_grad():
+        # raw launches go to the CURRENT HIP device: make it the tensors' device (the reference eval driver builds
+        # `cuda:N` tensors without torch.cuda.set_device, src/ts_hear_test.py:175)
+        with torch.no_grad(), _device_of(x):
             pk = self._weights(dev)
             ws = self._workspace(Bn, T, dev)
             st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
@@ -392,12 +409,15 @@ class Net(nn.Module):
         pk = self._weights(embed.device)
         st = torch.cuda.current_stream(embed.device).cuda_stream if embed.is_cuda else 0
         P = lambda t: t.data_ptr()
-        lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]), P(pk["emb_ln_b"]),
-                 P(gain_raw), P(gain), embed.shape[0], st)
+        with _device_of(embed):
+            lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]), P(pk["emb_ln_b"]),
+                     P(gain_raw), P(gain), embed.shape[0], st)
 
-    def _stream_chunk(self, x, gain, sin: dict, sout: dict, rings, pos, y):
+    def _stream_chunk(self, x, gain, sin: dict, sout: dict, rings, pos, y, pk: dict, ws: dict):
         """One chunk of ONE frame for `Streamer`: the launches of `_separate` with every state tensor read from `sin` and
-        written to `sout` (preallocated), the K / V history in per-block persistent rings, the speaker gain given."""
+        written to `sout` (preallocated), the K / V history in per-block persistent rings, the speaker gain given.
+        `pk` / `ws`: the packed weights and the T=1 workspace, OWNED by the caller — a captured graph holds raw pointers
+        into them, so they must not be the entries `_weights` / `_workspace` may replace or evict later."""
         lib = self._lib(x)
         dev = x.device
         hop, nfft = self.stft_chunk_size, self.nfft
@@ -405,8 +425,6 @@ class Net(nn.Module):
         T = (n - nfft) // hop + 1
         assert T == 1 and n == nfft, "the streaming path takes chunks of stft_chunk_size + stft_pad_size samples"
         F_, H_ = self.n_freqs, self.hidden
-        pk = self._weights(dev)
-        ws = self._workspace(Bn, T, dev)
         st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
         P = lambda t: t.data_ptr()
         xa, xb, xc, hbuf = ws["xa"], ws["xb"], ws["xc"], ws["hbuf"]
@@ -475,6 +493,14 @@ class Streamer:
         self.parity = 0
         self.graphs = None
         self.graph = None
+        # strong references: the captured graphs bake in pointers into the packed weights and the T=1 workspace.
+        # `Net._workspace` evicts its cache after a few shapes and `Net._weights` re-packs after any parameter change;
+        # holding the objects here keeps the memory alive, and `step` refuses to replay once the weights were re-packed.
+        with torch.no_grad(), _device_of(self.chunk):
+            self._pk = net._weights(dev)
+            self._pack_key = net._pack_key
+            self._ws = net._workspace(B, 1, dev)
+            net._ws.pop((B, 1, str(dev)), None)          # private to this streamer from now on
         if use_graph and dev.type == "cuda":
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -492,8 +518,12 @@ class Streamer:
             self.reset()
 
     def _body(self, k: int):
-        self.net._stream_chunk(self.chunk, self.gain, self.sets[k], self.sets[k ^ 1], self.rings, self.pos, self.out)
-        self.pos.add_(1)
+        with _device_of(self.chunk):
+            self.net._stream_chunk(self.chunk, self.gain, self.sets[k], self.sets[k ^ 1], self.rings, self.pos, self.out,
+                                   self._pk, self._ws)
+            # ring slot counter, kept in [0, window): an ever-growing int32 would go negative after 2^31 chunks and C's
+            # `%` would then index before the ring
+            self.pos.add_(1).remainder_(self.net.local_atten_len)
 
     def reset(self):
         for st in self.sets:
@@ -512,6 +542,9 @@ class Streamer:
 
     def step(self, chunk: torch.Tensor) -> torch.Tensor:
         """chunk [B, 2, 192] (128 new + 64 look-ahead samples) -> [B, 2, 128]."""
+        if self.net._weights(self.device) is not self._pk:
+            raise RuntimeError("the Net's parameters changed after this Streamer was built (its HIP graphs hold pointers "
+                               "into the old packed weights): create a new streamer with net.make_streamer(...)")
         self.chunk.copy_(chunk)
         with torch.no_grad():
             if self.graphs is not None:

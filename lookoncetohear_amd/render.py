@@ -56,6 +56,7 @@ class BinauralRenderer:
         peak = torch.empty(B, dtype=torch.int32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream if srcs.is_cuda else 0
         P = lambda t: t.data_ptr()
-        lib.call("lh_render_binaural", P(srcs), P(rirs), P(gains), P(tgt_idx), P(events), P(peak), P(mixture), P(target),
-                 B, S1, N, Lh, st)
+        with _cabi.device_of(srcs):
+            lib.call("lh_render_binaural", P(srcs), P(rirs), P(gains), P(tgt_idx), P(events), P(peak), P(mixture),
+                     P(target), B, S1, N, Lh, st)
         return mixture, target, peak.view(torch.float32), events

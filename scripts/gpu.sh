@@ -1,0 +1,58 @@
+#!/bin/bash
+# One entry point for everything that runs on the MI355X box through gpurun:
+#     gpurun --timeout 900 -- 'bash scripts/gpu.sh <task> [args]'
+# Tasks write their results under gpurun_out/ (merged back by gpurun); the summaries worth keeping are copied into
+# profiles/ by hand afterwards.
+set -u
+R=$PWD
+mkdir -p gpurun_out
+task=${1:-check}; shift || true
+
+bench_line() {      # bench_line <json file> <label>: one human-readable line from a bench.py JSON line
+python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print('%-30s ms/step %.3f  %.4g %s' % (sys.argv[2], d['ms_per_step'], d['value'], d['unit']),
+          {k: round(v, 3) for k, v in d.get('kernels_ms_per_step', {}).items()})
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+}
+
+case $task in
+ubench)             # per-SIMD issue model micro-benchmark (scripts/ubench/gen_issue_model.py; binary built on the CPU side)
+    timeout 300 scripts/ubench/issue_model > gpurun_out/ubench_issue_model.txt 2>&1; echo "rc=$?"
+    cat gpurun_out/ubench_issue_model.txt ;;
+check)              # GPU parity suite + bench lines (batch 32, batch 1, streaming)
+    timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
+    for a in "--batch 32" "--batch 1" "--mode stream"; do
+        timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline $a > gpurun_out/bench_chk.json 2>> gpurun_out/bench.err
+        bench_line gpurun_out/bench_chk.json "$a"
+    done ;;
+ab)                 # same-box A/B of library builds: LIBS="_lookonce_hip_x.so _lookonce_hip.so" BATCH=32 REPS=2
+    for rep in $(seq ${REPS:-2}); do for lib in ${LIBS:-_lookonce_hip.so}; do for b in ${BATCH:-32}; do
+        LOOKONCE_HIP_LIB=$R/lookoncetohear_amd/$lib timeout 200 python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-secondary --batch $b ${BENCH_ARGS:-} > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
+        bench_line gpurun_out/bench_ab.json "$lib B=$b"
+    done; done; done ;;
+bench)              # the default bench line, as the driver runs it
+    timeout 900 python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+    cut -c1-3000 gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
+profile)            # rocprofv3 kernel stats + PMC passes (separate runs) of the B=32 bench; then the bench line itself
+    cd /tmp && export TMPDIR=/tmp
+    P="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
+    timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o r1 -- $P > $R/gpurun_out/prof_stats.log 2>&1; echo "rocprof rc=$?"
+    python $R/scripts/rocpd_summary.py /tmp/prof_stats/r1_results.db $R/gpurun_out/kernel_stats.csv
+    for C in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$C -o r1 -- $P > $R/gpurun_out/prof_$C.log 2>&1; echo "rocprof $C rc=$?"
+        python $R/scripts/rocpd_summary.py /tmp/prof_$C/r1_results.db $R/gpurun_out/pmc_$C.csv --pmc
+    done
+    python $R/scripts/make_pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv 32 $R/gpurun_out/pmc_traffic.json
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_sq -o r1 -- $P > $R/gpurun_out/prof_sq.log 2>&1; echo "rocprof sq rc=$?"
+    python $R/scripts/rocpd_summary.py /tmp/prof_sq/r1_results.db $R/gpurun_out/pmc_sq.csv --pmc
+    timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM -d /tmp/prof_sq2 -o r1 -- $P > $R/gpurun_out/prof_sq2.log 2>&1; echo "rocprof sq2 rc=$?"
+    python $R/scripts/rocpd_summary.py /tmp/prof_sq2/r1_results.db $R/gpurun_out/pmc_sq2.csv --pmc
+    cd $R
+    head -40 gpurun_out/kernel_stats.csv; head -60 gpurun_out/pmc_traffic.json ;;
+*)  echo "unknown task $task"; exit 2 ;;
+esac

@@ -61,6 +61,6 @@ def test_dropin_surface():
     ref = O.init_state(cfg, 3)
     assert {k: tuple(v.shape) for k, v in O.flat_state(st).items()} == {k: tuple(v.shape) for k, v in O.flat_state(ref).items()}
     with pytest.raises(RuntimeError, match="no CPU"):
-        net(torch.zeros(1, 2, 1000), torch.zeros(1, 1, 256))
+        net.eval()(torch.zeros(1, 2, 1000), torch.zeros(1, 1, 256))
     with pytest.raises(NotImplementedError):
         Net()                                                           # reference defaults: unsupported shapes

@@ -71,3 +71,38 @@ def test_si_snr_definition():
     assert torch.allclose(v, O.si_snr(3.0 * p + 1.0, t), atol=1e-3)
     assert v.shape == (3, 2) and (v > 10).all() and (v < 30).all()
     assert O.si_snr_i(p, p, t).abs().max() < 1e-5
+
+
+def test_package_random_init_weights_equal_the_oracles(oracle_cfg_sd):
+    """bench.py / smoke() draw their random-init weights from lookoncetohear_amd.config (the product side must not
+    import oracle/); the oracle keeps its own copy of the rules.  Both must be the same tensors, bit for bit — the
+    committed goldens were generated from the oracle's."""
+    from lookoncetohear_amd import config
+    from oracle import embedder_oracle as E
+    _, sd = oracle_cfg_sd
+    assert config.TSH_PARAMS == O.TSH_PARAMS and config.EMBED_PARAMS == E.EMBED_PARAMS
+    mine = config.separator_weights(0)
+    assert mine.keys() == sd.keys()
+    for k in sd:
+        assert torch.equal(mine[k], sd[k]), k
+    esd = E.synthetic_state_dict(E.ECfg(**E.EMBED_PARAMS), 3)
+    emine = config.embedder_weights(3)
+    assert emine.keys() == esd.keys()
+    for k in esd:
+        assert torch.equal(emine[k], esd[k]), k
+
+
+def test_foreign_filterbank_keys_are_dropped_and_training_forward_is_refused(oracle_cfg_sd):
+    """A reference checkpoint may carry asteroid's second filterbank buffer (`torch_window`); it must not break the
+    strict load.  And the drop-in refuses a grad-enabled training-mode forward instead of returning a graph-less
+    tensor that `loss.backward()` would choke on."""
+    import pytest
+    from lookoncetohear_amd.net import Net
+    _, sd = oracle_cfg_sd
+    sd2 = dict(sd)
+    sd2["tfgridnet.enc.filterbank.torch_window"] = torch.zeros(192)
+    sd2["tfgridnet.dec.filterbank.torch_window"] = torch.zeros(192)
+    net = Net(**O.TSH_PARAMS)
+    net.load_state_dict(sd2, strict=True)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        net(torch.zeros(1, 2, 1000), torch.zeros(1, 1, 256))
