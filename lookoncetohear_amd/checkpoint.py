@@ -141,6 +141,16 @@ def import_packed(path: str, device="cpu") -> Tuple[dict, Dict[str, torch.Tensor
     return meta, out
 
 
+def run_packed(path: str, x: torch.Tensor, embed: torch.Tensor) -> torch.Tensor:
+    """Offline separation `x [B, 2, N]`, `embed [B, 256]` -> `[B, 2, N]` driven by a packed blob alone (no state dict,
+    no parameter tree): what a C host does with `include/lookonce_weights.h` + `include/lookonce_hip.h`."""
+    from .net import Net
+    net = Net.from_packed(path, x.device)
+    with torch.no_grad():
+        y, _ = net.predict(x, embed, None, pad=True, want_state=False)
+    return y
+
+
 def _main(argv):
     if len(argv) >= 2 and argv[0] == "info":
         meta, start = read_index(argv[1])

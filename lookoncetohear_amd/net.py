@@ -161,6 +161,7 @@ class Net(nn.Module):
         self._packed = None
         self._ws: Dict[tuple, dict] = {}
         self._zeros: Dict[tuple, dict] = {}
+        self._blob = None                  # (device, packed tree) when built by `from_packed`
         self._lib_override = None          # TEST HOOK ONLY (tests/hipemu): never set on the product path
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: list of (kernel tag, start event, end event) per launch
@@ -225,7 +226,35 @@ class Net(nn.Module):
                                "path. Move the module and its inputs to cuda.")
         return _cabi.load()
 
+    @classmethod
+    def from_packed(cls, path: str, device) -> "Net":
+        """A separator whose weights come ONLY from a packed blob (`checkpoint.export_packed`, format in
+        include/lookonce_weights.h): the blob's payload is uploaded in one copy and its tensors are handed to the C ABI
+        as they are.  The parameter tree is dropped (nothing to pack, nothing to load) — this is the host a Python-free
+        caller of the C ABI would write, with the launch sequence of `_separate`."""
+        from . import checkpoint
+        meta, flat = checkpoint.import_packed(path, device)
+        if meta["model"] != "separator":
+            raise ValueError(f"{path}: holds a {meta['model']!r} blob")
+        if meta["abi_version"] != _cabi.ABI_VERSION:
+            raise ValueError(f"{path}: packed for ABI v{meta['abi_version']}, library is v{_cabi.ABI_VERSION}")
+        net = cls(**meta["params"]).eval()
+        net.tfgridnet = None                                     # no parameters: the blob is the only weight source
+        tree: dict = {"blocks": [dict() for _ in range(net.n_blocks)]}
+        for name, t in flat.items():
+            if name.startswith("blocks."):
+                _, i, key = name.split(".", 2)
+                tree["blocks"][int(i)][key] = t
+            else:
+                tree[name] = t
+        net._blob = (next(iter(flat.values())).device, tree)
+        return net
+
     def _weights(self, device) -> dict:
+        if self._blob is not None:
+            if torch.device(device) != self._blob[0]:
+                raise RuntimeError(f"packed weights live on {self._blob[0]}, input on {device}")
+            return self._blob[1]
         tensors = list(self.parameters()) + list(self.buffers())
         key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
         if key != self._pack_key:

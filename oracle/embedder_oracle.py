@@ -1,6 +1,10 @@
 """TEST INFRASTRUCTURE — CPU oracle for the enrollment embedder (BASELINE configs[4]).
 
-PARITY UNPINNED.  `EmbedTFGridNet` (reference src/models/tfgridnet_orig/tfgridnet.py:88-127) subclasses
+PARITY: FRONT END + HEAD PINNED, TRUNK BLOCKS UNPINNED.  oracle/check_embedder_against_reference.py runs the
+reference's own `Stft` copy (src/models/tfgridnet_orig/stft.py:32-233) and the reference's own
+`EmbedTFGridNet.forward` lines (tfgridnet.py:100-127) around a stub trunk and finds this file's `spec` tap bit-equal
+and its embedding equal to 4e-16 (fp64); fixtures in tests/golden/embedder_pinned_golden.npz.  What stays unpinned is
+the inside of the trunk blocks:  `EmbedTFGridNet` (reference src/models/tfgridnet_orig/tfgridnet.py:88-127) subclasses
 `espnet2.enh.separator.tfgridnet_separator.TFGridNet`, an un-vendored, un-pinned third-party dependency
 (`requirements.txt:19` lists `espnet` without a version) that is not installed here and whose source is not under
 /root/reference.  The trunk below (STFT encoder, Conv2d+GroupNorm, non-causal GridNetBlock with emb_ks=4 unfold
