@@ -33,10 +33,14 @@ enum {
 
 /* Contraction arithmetic of the recurrent kernels (argument `mode`):
  *   LH_GEMM_F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32); w_pk = fp32 image  [dirs][4][4][32][64]
- *   LH_GEMM_F16X3 split precision: each fp32 operand = fp16 hi + 2^-11 * fp16 lo, three fp16 MFMAs
- *                 (hi*hi, hi*lo, lo*hi) accumulated in fp32 (~22 mantissa bits);
- *                 w_pk = fp16 image [dirs][4 waves][4 gates][4 ksteps][64 lanes][hi 8 | lo 8] of
- *                 [W_ih * ln_w | W_hh] and b_sum = b_ih + b_hh + W_ih ln_b: the LayerNorm affine is folded into
+ *   LH_GEMM_F16X3 split precision: each fp32 operand = fp16 hi + fp16 lo, three fp16 MFMAs
+ *                 (hi*hi, hi*lo, lo*hi) accumulated in fp32 (~22 mantissa bits).  In the RECURRENT kernels
+ *                 (lh_ln_lstm_*, lh_intra_block, lh_inter_block) lo = fp16(v - hi) is NOT rescaled (fp16
+ *                 subnormals go through the matrix core at full value); every other split-precision image of
+ *                 this header stores lo = fp16((v - hi) * 2^11);
+ *                 w_pk = fp16 image [dirs][4 waves][4 gates][4 ksteps][64 lanes][hi 8 | lo 8] (lo unscaled) of
+ *                 [W_ih * ln_w | W_hh] and b_sum = b_ih + b_hh + W_ih ln_b, rows of both scaled by the exponent factor of their gate (-log2 e for i, f, o;
+ *                 -2 log2 e for g: weights.py gate_prescale). The LayerNorm affine is folded into
  *                 the image (weights.py pack_block), the kernel only standardises x; ln_w/ln_b are ignored  */
 enum { LH_GEMM_F32 = 0, LH_GEMM_F16X3 = 1 };
 
@@ -120,13 +124,14 @@ int lh_inter_matvec(const float* x, const void* wih_pk, const float* b_sum, cons
  * sequences and accumulates both halves of the projection into the same output rows (no hidden-state round trip).
  *   x, out [B*T][97][64] (must not alias); w_pk / b_sum as lh_ln_lstm_intra in LH_GEMM_F16X3 mode;
  *   wlin_pk [2 passes][4 ntiles][2 ksteps][64 lanes][hi 8 | lo 8] = intra_linear.weight[:, 0:64] and [:, 64:128]
- *   (weights.py pack_linear_f16x3); blin [64]
+ *   (weights.py pack_linear_f16x3(unscaled=True): lo = fp16(w - hi)); blin [64]
  */
 int lh_intra_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                    float* out, int n_frames, lh_stream_t stream);
 
 /* A.3.2 + Linear fused: LayerNorm -> causal LSTM over time (state in/out) -> Linear(64->64) -> + residual;
- * replaces tfgridnet_causal.py:521-538.   x, out [B][T][97][64]; wlin_pk [4][2][64][16] fp16 hi/lo; blin [64]
+ * replaces tfgridnet_causal.py:521-538.   x, out [B][T][97][64]; wlin_pk [4][2][64][16] fp16 hi/lo (lo unscaled,
+ * weights.py `inter_lin_wu`); blin [64]
  */
 int lh_inter_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                    const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,
@@ -277,6 +282,20 @@ int lh_render_binaural(const float* src, const float* rir, const float* gain, co
 int lh_metric_sums(const float* outputs, const float* target, const float* mixture, const float* emb,
                    const float* emb_gt, double* scratch, float* rows, double* sums, int B, int n_samples,
                    int emb_dim, lh_stream_t stream);
+
+/* The path's ONE exchange step, for hosts that drive this ABI without Python: all-reduce (sum) of the
+ * fp64 metric sums written by lh_metric_sums over one process per GPU — RCCL over xGMI, 32 bytes, latency-bound.
+ * Replaces the reference's Lightning `sync_dist` all-reduce (src/ts_hear_embed_pl_module.py:82-107).  RCCL is bound
+ * with dlopen at the first call (LOOKONCE_RCCL_LIB overrides the name; an RCCL already mapped into the process is
+ * reused): LH_ERR_UNSUPPORTED when no RCCL can be found.  The Python host uses torch.distributed instead.
+ *   lh_comm_unique_id  rank 0: 128 opaque bytes to hand to every rank through the host's own channel (ncclGetUniqueId)
+ *   lh_comm_init       collective over all ranks, on each rank's current device (ncclCommInitRank)
+ *   lh_allreduce_f64   in place, on `stream` (ncclAllReduce, ncclFloat64, ncclSum)
+ */
+int lh_comm_unique_id(void* id128);
+int lh_comm_init(const void* id128, int n_ranks, int rank, void** comm);
+int lh_allreduce_f64(void* comm, double* buf, int count, lh_stream_t stream);
+int lh_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

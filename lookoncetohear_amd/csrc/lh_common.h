@@ -56,6 +56,18 @@ __device__ __forceinline__ void lstm_cell(float gi, float gf, float gg, float go
     c = cc;
     h = og * tanh_f(cc);
 }
+// The same cell on PRE-SCALED gate pre-activations: the packed weights / biases of the split-precision recurrent kernels
+// carry the exponent scale (rows i, f, o times -log2 e, rows g times -2 log2 e: weights.py GATE_PRESCALE), so
+// sigma = rcp(1 + exp2(a)) and tanh = 2 rcp(1 + exp2(a)) - 1 need no multiply on the way in (16 VALU per step).
+__device__ __forceinline__ void lstm_cell_pre(float ai, float af, float ag, float ao, float& c, float& h) {
+    const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ai));
+    const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(af));
+    const float g2 = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ag)) - 1.0f;
+    const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ao));
+    const float cc = fg * c + ig * g2;
+    c = cc;
+    h = og * tanh_f(cc);
+}
 __device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
 
 // sum over the 64 lanes of a wave (every lane gets the total): 4 DPP row steps + 2 cross-row shuffles
@@ -94,6 +106,17 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
+}
+
+// "The value of v is decided HERE": an empty volatile asm that claims to rewrite the registers.  Arithmetic on a global
+// load's result cannot be hoisted above it — used at the top of an unrolled recurrent step so the consumer of a load
+// issued one step earlier (and its s_waitcnt vmcnt) stays behind the step barrier instead of landing right after the load.
+__device__ __forceinline__ void pin_here(float4& v) {
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+#else
+    (void)v;
+#endif
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LH_OK : LH_ERR_LAUNCH; }

@@ -10,6 +10,8 @@
 //     one barrier per step); k is permuted so each lane reads 32 contiguous floats (ds_read_b128);
 //   * exact fp32 MFMA (bitwise an fmaf chain) keeps the 625-step recurrences inside the 1e-3 budget;
 //   * x_{t+1} is fetched and normalised while step t computes; h_t is written back coalesced from LDS.
+#include <type_traits>
+
 #include "lh_common.h"
 
 namespace lh {
@@ -187,10 +189,14 @@ __global__ void __launch_bounds__(256) k_ln_lstm(const float* __restrict__ x, co
 
 // ------------------------------------------------------------------------------------------------------
 // Split-precision variant ("f16x3"): every fp32 operand v is carried as two fp16 numbers
-//     hi = fp16(v),  lo = fp16((v - hi) * 2^11)                     (v - hi is exact in fp32)
-// and a product a*b is evaluated as  hi_a*hi_b + 2^-11 * (hi_a*lo_b + lo_a*hi_b)  on v_mfma_f32_16x16x32_f16
-// (fp16 products are exact in the fp32 accumulator; the dropped lo*lo term is 2^-22 relative).  That keeps
-// ~22 mantissa bits — the measured end-to-end error stays at the 1e-5 level against the 1e-3 budget — while
+//     hi = fp16(v),  lo = fp16(v - hi)                              (v - hi is exact in fp32)
+// and a product a*b is evaluated as  hi_a*hi_b + hi_a*lo_b + lo_a*hi_b  on v_mfma_f32_16x16x32_f16, all three into
+// ONE fp32 accumulator (fp16 products are exact in it; the dropped lo*lo term is 2^-22 relative).  `lo` is NOT
+// rescaled: the matrix core takes fp16 subnormals at full value (scripts/ubench/gen_issue_model.py denorm_test,
+// profiles/r02a_ubench_issue_model.txt), so lo keeps 11 bits while |v| >= 2^-3 and an absolute 2^-25 below that —
+// for the operands of these kernels (LayerNorm outputs, h in (-1, 1), weights of O(0.1)) that is the fp32 noise level.
+// Not rescaling saves the second accumulator set (16 VGPRs), the 2^-11 recombination (16 + 4 VALU per step) and one
+// multiply per split element.  The measured end-to-end error stays at the 1e-6 level against the 1e-3 budget, while
 // the three fp16 MFMAs (K=32 each) cost ~1/5 of the fp32 MFMA (K=4) they replace.  Same persistent structure:
 // weights resident in VGPRs (now as hi/lo fp16 fragments, same 128 registers), A = [LN(x_t) | h_{t-1}] staged
 // in LDS as fp16 hi/lo rows, one barrier per step.
@@ -199,11 +205,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int LH_AP = 144;      // fp16 elements per LDS row: 128 + 16 pad (288 B: conflict-free ds_read_b128)
 constexpr int LH_HP = 68;       // fp32 copy of h: 64 + 4 pad
-constexpr float SPLIT_SCALE = 2048.0f;
 
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
-    lo = (_Float16)((v - (float)hi) * SPLIT_SCALE);
+    lo = (_Float16)(v - (float)hi);
 }
 
 template <int MT>
@@ -327,30 +332,23 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__
         // Per 16-sequence tile: 48 MFMAs, then the two split accumulators collapse to 16 gate pre-activations so
         // the accumulator registers are free again; with MT = 2 the second tile's MFMAs have no dependence on the
         // first tile's cell update and the scheduler overlaps matrix and VALU work inside the wave.
-        constexpr float INV = 1.0f / SPLIT_SCALE;
         f32x4 gate[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            f32x4 accm[4], accc[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                accm[g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
-                accc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int g = 0; g < 4; ++g) gate[m][g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
             const int ro = (cur * NS + m * 16 + l15) * LH_AP + g4 * 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) accm[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], accm[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], gate[m][g], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], accc[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], gate[m][g], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], accc[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], gate[m][g], 0, 0, 0);
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gate[m][g] = accm[g] + accc[g] * INV;
         }
 
         const int unit = wave * 16 + l15;
@@ -359,7 +357,7 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float hv;
-                lstm_cell(gate[m][0][r], gate[m][1][r], gate[m][2][r], gate[m][3][r], creg[m][r], hv);
+                lstm_cell_pre(gate[m][0][r], gate[m][1][r], gate[m][2][r], gate[m][3][r], creg[m][r], hv);
                 const int rl = m * 16 + g4 * 4 + r;
                 _Float16 th, tl;
                 split_f16(hv, th, tl);
@@ -410,7 +408,7 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
                                                         const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
                                                         const float* __restrict__ blin, const float* __restrict__ h0,
                                                         const float* __restrict__ c0, float* __restrict__ hN,
-                                                        float* __restrict__ cN, float* __restrict__ out, int nseq,
+                                                        float* __restrict__ cN, float* out, int nseq,
                                                         int nstep, int sdiv, int so, int si, int ps, int dir,
                                                         int accumulate, int dephase) {
     constexpr int NS = 16 * MT;
@@ -418,14 +416,12 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
     __shared__ __attribute__((aligned(16))) float ls[2 * NS * LSP];
-    __shared__ __attribute__((aligned(16))) _Float16 wls[4 * 2 * 64 * 16];        // output-projection B image of this pass
-    __shared__ __attribute__((aligned(16))) float hf[NS * LSP];                   // fp32 copy of the newest hidden state
+    __shared__ __attribute__((aligned(16))) float hf[NS * LSP];                   // fp32 copy of the final hidden state
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s0 = blockIdx.x * NS;
     const int g4 = lane >> 4, l15 = lane & 15;
     const int q = tid & 15;
     const int unit = wave * 16 + l15;
-    constexpr float INV = 1.0f / SPLIT_SCALE;
     // The two workgroups sharing a CU start together and, with fair issue arbitration, stay phase-locked: both in the
     // MFMA phase, then both in the activation (VALU) phase, so the matrix and vector pipes never overlap.  Giving the
     // wave in the odd hardware slot a higher issue priority breaks the symmetry: it wins the MFMA pipe, reaches its
@@ -435,203 +431,259 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
         if (hw_id & 1) __builtin_amdgcn_s_setprio(2);
     }
 
-    auto row_of = [&](int s, int p) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si + (long)p * ps; };
+    // Addressing.  row(s, p) = (s / sdiv) * so + (s % sdiv) * si + p * ps  (256-byte activation rows).  Per thread only
+    // the sequence part varies and it is loop-invariant; the step part p * ps is wave-uniform.  So every global access
+    // of the step loop is  (uniform 64-bit base of the workgroup's first row, advanced per step on the scalar unit) +
+    // (a 32-bit per-thread byte offset computed once): no vector address arithmetic inside the loop.
+    auto row_of0 = [&](int s) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si; };
+    const long wg_row0 = row_of0(min(s0, nseq - 1));
+    unsigned voff[MT];                              // bytes from the workgroup's first row to this thread's float4
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);      // tail rows replicate sequence nseq-1
+        voff[i] = (unsigned)((row_of0(s) - wg_row0) * (C * 4) + q * 16);
+    }
+    const char* xb = reinterpret_cast<const char*>(x) + wg_row0 * (C * 4);
+    char* ob = reinterpret_cast<char*>(out) + wg_row0 * (C * 4);
+    const long step_bytes = (long)ps * (C * 4);
+    auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
+
+    // weights of this pass: gate image and this wave's 16 output-projection columns, both resident in VGPRs
+    f16x8 wh[4][4], wl[4][4];
     {
-        const int pass = dir;
-        auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
-        // weights of this pass: gate image in VGPRs, output-projection image in LDS
-        f16x8 wh[4][4], wl[4][4];
-        {
-            const _Float16* wp = w_pk + ((long)(dir * 4 + wave) * 16 * 64 + lane) * 16;
+        const _Float16* wp = w_pk + ((long)(dir * 4 + wave) * 16 * 64 + lane) * 16;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    wh[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16);
-                    wl[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16 + 8);
-                }
-        }
-        for (int i = tid; i < 4 * 2 * 64 * 2; i += 256)
-            *reinterpret_cast<f16x8*>(&wls[i * 8]) = *reinterpret_cast<const f16x8*>(&wlin_pk[i * 8]);
-        float bias[4];
+            for (int ks = 0; ks < 4; ++ks) {
+                wh[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16);
+                wl[g][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(g * 4 + ks) * 64 * 16 + 8);
+            }
+    }
+    f16x8 lwh[2], lwl[2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + unit];
+    for (int ks = 0; ks < 2; ++ks) {
+        lwh[ks] = *reinterpret_cast<const f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16]);
+        lwl[ks] = *reinterpret_cast<const f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16 + 8]);
+    }
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = b_sum[dir * 256 + g * 64 + unit];
+    const float lbias = accumulate ? 0.0f : blin[unit];       // output bias rides in the accumulator (first pass only)
 
-        auto load_x = [&](int it, float4 (&xr)[MT]) {
-            const int p = step_pos(it);
+    // LDS addresses (in halves / floats) of this thread's roles; the double-buffer index is a compile-time constant of
+    // the 2x unrolled step loop, so all of them are immediates on top of these bases
+    int a_row[MT], l_row[MT];                       // row-wise role: row (tid >> 4), float4 q
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
-                xr[i] = *reinterpret_cast<const float4*>(&x[row_of(s, p) * C + q * 4]);
-            }
-        };
-        auto store_split4 = [&](int buf, int rl, int col, float a, float b, float c, float d) {
-            f16x4 h4, l4;
-            _Float16 th, tl;
-            split_f16(a, th, tl); h4[0] = th; l4[0] = tl;
-            split_f16(b, th, tl); h4[1] = th; l4[1] = tl;
-            split_f16(c, th, tl); h4[2] = th; l4[2] = tl;
-            split_f16(d, th, tl); h4[3] = th; l4[3] = tl;
-            *reinterpret_cast<f16x4*>(&ahi[(buf * NS + rl) * LH_AP + col]) = h4;
-            *reinterpret_cast<f16x4*>(&alo[(buf * NS + rl) * LH_AP + col]) = l4;
-        };
-        auto norm_store_x = [&](int buf, float4 (&xr)[MT]) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int rl = (tid + 256 * i) >> 4;
-                float4 v = xr[i];
-                const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
-                v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-                const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
-                const float rstd = rsqrtf(var + LN_EPS);
-                store_split4(buf, rl, q * 4, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
-            }
-        };
-        // base of the projection's accumulation for the rows of step `it`: pass 0 the residual (= the un-normalised
-        // LSTM input itself), pass 1 the partial sum written by pass 0 (same thread, same rows)
-        auto load_base = [&](int it, float4 (&rr)[MT]) {
-            const int p = step_pos(it);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
-                const float* src = accumulate ? out : x;
-                rr[i] = *reinterpret_cast<const float4*>(&src[row_of(s, p) * C + q * 4]);
-            }
-        };
-        // finished rows of step `it`: base + (bias) + projection parked in ls[buf]
-        auto store_rows = [&](int it, int buf, const float4 (&rr)[MT]) {
-            const int p = step_pos(it);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int rl = (tid + 256 * i) >> 4;
-                const int s = min(s0 + rl, nseq - 1);        // tail rows replicate sequence nseq-1: identical bytes
-                const float4 pv = *reinterpret_cast<const float4*>(&ls[(buf * NS + rl) * LSP + q * 4]);
-                *reinterpret_cast<float4*>(&out[row_of(s, p) * C + q * 4]) =
-                    make_float4(rr[i].x + pv.x, rr[i].y + pv.y, rr[i].z + pv.z, rr[i].w + pv.w);
-            }
-        };
-        // P = h W_lin^T for the h tile in A buffer `buf` -> ls[lbuf]   (k-steps 2,3 of the A rows are the h part)
-        const float lbias = accumulate ? 0.0f : blin[unit];       // output bias rides in the accumulator (first pass only)
-        auto lin_tile = [&](int buf, int lbuf) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x4 am = f32x4{lbias, lbias, lbias, lbias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int ro = (buf * NS + m * 16 + l15) * LH_AP + g4 * 8;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const f16x8 bh = *reinterpret_cast<const f16x8*>(&wls[((wave * 2 + ks) * 64 + lane) * 16]);
-                    const f16x8 bl = *reinterpret_cast<const f16x8*>(&wls[((wave * 2 + ks) * 64 + lane) * 16 + 8]);
-                    const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + (2 + ks) * 32]);
-                    const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + (2 + ks) * 32]);
-                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, am, 0, 0, 0);
-                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, ac, 0, 0, 0);
-                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, ac, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ls[(lbuf * NS + m * 16 + g4 * 4 + r) * LSP + unit] = am[r] + ac[r] * INV;
-            }
-        };
+    for (int i = 0; i < MT; ++i) {
+        a_row[i] = ((tid + 256 * i) >> 4) * LH_AP + q * 4;
+        l_row[i] = ((tid + 256 * i) >> 4) * LSP + q * 4;
+    }
+    const int a_frag = l15 * LH_AP + g4 * 8;        // MFMA A fragment: row l15 (+16 m), halves g4*8 (+32 ks)
+    const int a_cell = (g4 * 4) * LH_AP + C + unit; // cell role: rows g4*4 + r (+16 m), hidden column `unit`
+    const int l_cell = (g4 * 4) * LSP + unit;
 
-        // ---- prologue
-        float creg[MT][4];
-        float4 xr[MT], rr[MT];
-        {
-            load_x(0, xr);
-            norm_store_x(0, xr);
-            load_x(1, xr);
+    auto load_x = [&](int it, float4 (&xr)[MT]) {
+        const char* base = xb + step_pos(it) * step_bytes;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int rl = (tid + 256 * i) >> 4;
-                const int s = min(s0 + rl, nseq - 1);
-                float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
-                store_split4(0, rl, C + q * 4, hv.x, hv.y, hv.z, hv.w);
-                rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < MT; ++i) xr[i] = *reinterpret_cast<const float4*>(base + voff[i]);
+    };
+    auto store_split4 = [&](int idx, float a, float b, float c, float d) {
+        f16x4 h4, l4;
+        _Float16 th, tl;
+        split_f16(a, th, tl); h4[0] = th; l4[0] = tl;
+        split_f16(b, th, tl); h4[1] = th; l4[1] = tl;
+        split_f16(c, th, tl); h4[2] = th; l4[2] = tl;
+        split_f16(d, th, tl); h4[3] = th; l4[3] = tl;
+        *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
+        *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
+    };
+    auto norm_store_x = [&](int buf, float4 (&xr)[MT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float4 v = xr[i];
+            const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+            v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+            const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+            const float rstd = __builtin_amdgcn_rsqf(var + LN_EPS);      // var + eps >= 1e-5: no denormal guard needed
+            store_split4(buf * NS * LH_AP + a_row[i], v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
+        }
+    };
+    // base of the projection's accumulation for the rows of step `it`: pass 0 the residual (= the un-normalised
+    // LSTM input itself), pass 1 the partial sum written by pass 0 (same thread, same rows)
+    auto load_base = [&](int it, float4 (&rr)[MT]) {
+        const char* base = (accumulate ? const_cast<const char*>(ob) : xb) + step_pos(it) * step_bytes;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) rr[i] = *reinterpret_cast<const float4*>(base + voff[i]);
+    };
+    // finished rows of step `it`: base + (bias) + projection parked in ls[buf]
+    auto store_rows = [&](int it, int buf, const float4 (&rr)[MT]) {
+        char* base = ob + step_pos(it) * step_bytes;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[buf * NS * LSP + l_row[i]]);
+            *reinterpret_cast<float4*>(base + voff[i]) =
+                make_float4(rr[i].x + pv.x, rr[i].y + pv.y, rr[i].z + pv.z, rr[i].w + pv.w);
+        }
+    };
+    // P = h W_lin^T for the h tile in A buffer `buf` -> ls[lbuf]   (k-steps 2,3 of the A rows are the h part)
+    auto lin_tile = [&](int buf, int lbuf) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 am = f32x4{lbias, lbias, lbias, lbias};
+            const int ro = (buf * NS + m * 16) * LH_AP + a_frag;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + (2 + ks) * 32]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + (2 + ks) * 32]);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwh[ks], am, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwl[ks], am, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, lwh[ks], am, 0, 0, 0);
             }
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s = min(s0 + m * 16 + g4 * 4 + r, nseq - 1);
-                    creg[m][r] = c0 ? c0[(long)s * H + unit] : 0.0f;
-                }
+            for (int r = 0; r < 4; ++r) ls[(lbuf * NS + m * 16 + r) * LSP + l_cell] = am[r];
         }
+    };
+
+    // ---- prologue
+    float creg[MT][4], hreg[MT][4];                  // cell state; newest hidden state in fp32 (for the carried state)
+    float4 xr[MT], rr[MT];
+    {
+        load_x(0, xr);
+        norm_store_x(0, xr);
+        load_x(1, xr);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int s = min(s0 + ((tid + 256 * i) >> 4), nseq - 1);
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
+            store_split4(a_row[i] + C, hv.x, hv.y, hv.z, hv.w);
+            rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = min(s0 + m * 16 + g4 * 4 + r, nseq - 1);
+                creg[m][r] = c0 ? c0[(long)s * H + unit] : 0.0f;
+            }
+    }
+    __syncthreads();
+
+    // one step; CUR = A / projection buffer of this step (compile-time: the loop below is unrolled by two)
+    auto step = [&](int it, auto cur_tag) {
+        constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+        // Everything that CONSUMES global loads (x of step it+1 and the projection base of step it-2, both fetched one
+        // step ago) comes first, the step's own global traffic after it: the wave then waits once, at the top, for
+        // accesses issued a whole step earlier.  (With the store scheduled ahead of the x consumer the compiler has to
+        // wait for vmcnt(0) right behind the store, i.e. for the write acknowledge, every step: +20 % on the intra pass.)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {                // (also keeps the unrolled twin's consumers behind its barrier)
+            pin_here(xr[i]);
+            pin_here(rr[i]);
+        }
+        norm_store_x(nxt, xr);
+        float4 done[MT];                              // rows of step it-2: projection parked in ls[nxt] one step ago
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * LSP + l_row[i]]);
+            done[i] = make_float4(rr[i].x + pv.x, rr[i].y + pv.y, rr[i].z + pv.z, rr[i].w + pv.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (it >= 2) {
+            char* base = ob + step_pos(it - 2) * step_bytes;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) *reinterpret_cast<float4*>(base + voff[i]) = done[i];
+        }
+        load_base(it - 1, rr);                        // consumed next iteration (clamped at it = 0: unused)
+        load_x(it + 2, xr);
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x4 gate[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gate[m][g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
+            const int ro = (cur * NS + m * 16) * LH_AP + a_frag;
+#ifdef LH_LSTM_ACC2        // A/B variant: the two small products in a second accumulator chain (8 chains of depth 4 / 8)
+            f32x4 accc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) accc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], gate[m][g], 0, 0, 0);
+#ifdef LH_LSTM_ACC2
+#pragma unroll
+                for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], accc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], accc[g], 0, 0, 0);
+#else
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], gate[m][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], gate[m][g], 0, 0, 0);
+#endif
+            }
+#ifdef LH_LSTM_ACC2
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gate[m][g] += accc[g];
+#endif
+        }
+        lin_tile(cur, cur);                           // projection of h_{it-1} (at it = 0: of the initial state, unused)
+
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lstm_cell_pre(gate[m][0][r], gate[m][1][r], gate[m][2][r], gate[m][3][r], creg[m][r], hreg[m][r]);
+                _Float16 th, tl;
+                split_f16(hreg[m][r], th, tl);
+                ahi[(nxt * NS + m * 16 + r) * LH_AP + a_cell] = th;
+                alo[(nxt * NS + m * 16 + r) * LH_AP + a_cell] = tl;
+            }
         __syncthreads();
-
-        for (int it = 0; it < nstep; ++it) {
-            const int cur = it & 1, nxt = cur ^ 1;
-            // rows of step it-2 are complete: projection parked in ls[(it-1)&1] one step ago, base fetched one step ago
-            if (it >= 2) store_rows(it - 2, (it - 1) & 1, rr);
-            load_base(it - 1, rr);                        // consumed next iteration (clamped at it = 0: unused)
-            norm_store_x(nxt, xr);
-            load_x(it + 2, xr);
-
-            f32x4 gate[MT][4];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x4 accm[4], accc[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    accm[g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
-                    accc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                const int ro = (cur * NS + m * 16 + l15) * LH_AP + g4 * 8;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
-                    const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) accm[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], accm[g], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], accc[g], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], accc[g], 0, 0, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gate[m][g] = accm[g] + accc[g] * INV;
-            }
-            lin_tile(cur, it & 1);                        // projection of h_{it-1} (at it = 0: of the initial state, unused)
-
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float hv;
-                    lstm_cell(gate[m][0][r], gate[m][1][r], gate[m][2][r], gate[m][3][r], creg[m][r], hv);
-                    const int rl = m * 16 + g4 * 4 + r;
-                    _Float16 th, tl;
-                    split_f16(hv, th, tl);
-                    ahi[(nxt * NS + rl) * LH_AP + C + unit] = th;
-                    alo[(nxt * NS + rl) * LH_AP + C + unit] = tl;
-                    hf[rl * LSP + unit] = hv;
-                }
-            __syncthreads();
+    };
+    {
+        int it = 0;
+        for (; it + 1 < nstep; it += 2) {
+            step(it, std::integral_constant<int, 0>{});
+            step(it + 1, std::integral_constant<int, 1>{});
         }
+        if (it < nstep) step(it, std::integral_constant<int, 0>{});
+    }
 
-        // ---- drain: rows of the last two steps
-        if (nstep >= 2) store_rows(nstep - 2, (nstep - 1) & 1, rr);
-        load_base(nstep - 1, rr);
-        lin_tile(nstep & 1, nstep & 1);                   // projection of h_{nstep-1}
+    // ---- drain: rows of the last two steps
+    if (nstep >= 2) store_rows(nstep - 2, (nstep - 1) & 1, rr);
+    load_base(nstep - 1, rr);
+    lin_tile(nstep & 1, nstep & 1);                   // projection of h_{nstep-1}
+    __syncthreads();
+    store_rows(nstep - 1, nstep & 1, rr);
+    if (hN) {                                         // final hidden state: cell layout -> rows, through LDS
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hf[(m * 16 + r) * LSP + l_cell] = hreg[m][r];
         __syncthreads();
-        store_rows(nstep - 1, nstep & 1, rr);
-        if (hN) {                                         // hf was last written before the final loop barrier
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int rl = (tid + 256 * i) >> 4;
-                if (s0 + rl < nseq)
-                    *reinterpret_cast<float4*>(&hN[(long)(s0 + rl) * H + q * 4]) =
-                        *reinterpret_cast<const float4*>(&hf[rl * LSP + q * 4]);
+        for (int i = 0; i < MT; ++i) {
+            const int rl = (tid + 256 * i) >> 4;
+            if (s0 + rl < nseq)
+                *reinterpret_cast<float4*>(&hN[(long)(s0 + rl) * H + q * 4]) =
+                    *reinterpret_cast<const float4*>(&hf[l_row[i]]);
+        }
+    }
+    if (cN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = s0 + m * 16 + g4 * 4 + r;
+                if (s < nseq) cN[(long)s * H + unit] = creg[m][r];
             }
-        }
-        if (cN) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s = s0 + m * 16 + g4 * 4 + r;
-                    if (s < nseq) cN[(long)s * H + unit] = creg[m][r];
-                }
-        }
     }
 }
 

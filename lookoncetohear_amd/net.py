@@ -384,7 +384,7 @@ class Net(nn.Module):
                     lib.call("lh_inter_matvec", P(xb), P(bp["inter_s_wih"]), P(bp["inter_s_b"]), P(bp["inter_s_whh"]),
                              P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
                 elif fuse:
-                    lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
+                    lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
                              P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
                 else:
                     # inter: LN + causal LSTM over time with carried state -> Linear(64->64) + residual
@@ -466,7 +466,7 @@ class Net(nn.Module):
                      Bn * T, st)
             lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), Bn * T * F_,
                      2 * H_, st)
-            lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_w"]),
+            lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
                      P(bp["inter_lin_b"]), P(sin["h"][i]), P(sin["c"][i]), P(sout["h"][i]), P(sout["c"][i]), P(xc), Bn, T, st)
             lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
                      P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),

@@ -65,14 +65,38 @@ def split_f16(v: torch.Tensor):
     return hi, lo
 
 
+def split_f16_unscaled(v: torch.Tensor):
+    """fp32 -> (hi, lo) fp16 pair with v ~= hi + lo, lo NOT rescaled (it is an fp16 subnormal for |v| < 2^-3; the
+    matrix core takes subnormals at full value).  The recurrent kernels (lh_lstm.hip) use this form: all three partial
+    products then go into one accumulator."""
+    hi = v.float().half()
+    lo = (v.float() - hi.float()).half()
+    return hi, lo
+
+
+LOG2E = 1.4426950408889634
+
+
+def gate_prescale(n_hidden: int, device) -> torch.Tensor:
+    """Per-row factor of [W_ih | W_hh] and of the summed bias in the split-precision recurrent kernels (lh_lstm.hip,
+    lh_common.h lstm_cell_pre): sigma(a) = 1 / (1 + 2^(-log2e a)), tanh(a) = 2 / (1 + 2^(-2 log2e a)) - 1, so rows of the
+    gates i, f, o carry -log2e and rows of g carry -2 log2e and the kernel feeds the accumulators straight to v_exp_f32."""
+    f = torch.full((4, n_hidden), -LOG2E, dtype=torch.float64, device=device)
+    f[2] *= 2.0
+    return f.reshape(-1)
+
+
 def pack_lstm_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
-    """Split-precision image for v_mfma_f32_16x16x32_f16: [4 waves, 4 gates, 4 ksteps, 64 lanes, 2 (hi|lo), 8] fp16.
+    """Split-precision image for v_mfma_f32_16x16x32_f16: [4 waves, 4 gates, 4 ksteps, 64 lanes, 2 (hi|lo), 8] fp16
+    (lo unscaled, `split_f16_unscaled`).
 
     Lane l of (wave w, gate g, k-step ks) holds column g*H + 16w + (l & 15) of [W_ih | W_hh] at
-    k = ks*32 + (l >> 4)*8 + j, j = 0..7 (x channels 0..63, then hidden units 0..63)."""
+    k = ks*32 + (l >> 4)*8 + j, j = 0..7 (x channels 0..63, then hidden units 0..63); rows pre-scaled by
+    `gate_prescale` (the exponent scale of the gate non-linearities)."""
     H = w_hh.shape[1]
     assert H == 64 and tuple(w_ih.shape) == (4 * H, 64)
-    wcat = torch.cat([w_ih, w_hh], dim=1).float()               # [256, 128]
+    wcat = torch.cat([w_ih, w_hh], dim=1).double()              # [256, 128]
+    wcat = (wcat * gate_prescale(H, wcat.device)[:, None]).float()
     dev = wcat.device
     lane = torch.arange(64, device=dev)
     wave = torch.arange(4, device=dev)[:, None, None, None, None]
@@ -82,13 +106,14 @@ def pack_lstm_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
     col = gate * H + wave * 16 + (lane & 15)[None, None, None, :, None]
     k = ks * 32 + (lane >> 4)[None, None, None, :, None] * 8 + j
     frag = wcat[col, k]                                          # [4,4,4,64,8]
-    hi, lo = split_f16(frag)
+    hi, lo = split_f16_unscaled(frag)
     return torch.stack([hi, lo], dim=4).contiguous()             # [4,4,4,64,2,8]
 
 
-def pack_linear_f16x3(w: torch.Tensor) -> torch.Tensor:
+def pack_linear_f16x3(w: torch.Tensor, unscaled: bool = False) -> torch.Tensor:
     """w [N, K] -> split-precision B image [N/16, K/32, 64 lanes, 2 (hi|lo), 8] fp16 for v_mfma_f32_16x16x32_f16:
-    lane l of (n-tile nt, k-step ks) holds W[nt*16 + (l & 15)][ks*32 + (l >> 4)*8 + j], j = 0..7."""
+    lane l of (n-tile nt, k-step ks) holds W[nt*16 + (l & 15)][ks*32 + (l >> 4)*8 + j], j = 0..7.
+    `unscaled`: lo = fp16(w - hi) instead of fp16((w - hi) * 2^11) — the form the fused recurrent kernels take."""
     N, K = w.shape
     assert N % 16 == 0 and K % 32 == 0
     dev = w.device
@@ -98,7 +123,7 @@ def pack_linear_f16x3(w: torch.Tensor) -> torch.Tensor:
     j = torch.arange(8, device=dev)[None, None, None, :]
     n = nt * 16 + (lane & 15)[None, None, :, None]
     k = ks * 32 + (lane >> 4)[None, None, :, None] * 8 + j
-    hi, lo = split_f16(w.float()[n, k])
+    hi, lo = (split_f16_unscaled if unscaled else split_f16)(w.float()[n, k])
     return torch.stack([hi, lo], dim=3).contiguous()
 
 
@@ -116,35 +141,39 @@ def pack_block(sd: dict, pre: str) -> dict:
     out["intra_w16"] = torch.stack([
         pack_lstm_f16x3(fold_w(g("intra_rnn.weight_ih_l0"), iw), g("intra_rnn.weight_hh_l0")),
         pack_lstm_f16x3(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw), g("intra_rnn.weight_hh_l0_reverse"))])
-    out["intra_b16"] = torch.stack([
+    intra_b = torch.stack([
         fold_b(g("intra_rnn.weight_ih_l0"), ib, g("intra_rnn.bias_ih_l0"), g("intra_rnn.bias_hh_l0")),
         fold_b(g("intra_rnn.weight_ih_l0_reverse"), ib, g("intra_rnn.bias_ih_l0_reverse"),
                g("intra_rnn.bias_hh_l0_reverse"))])
+    inter_b = fold_b(g("inter_rnn.weight_ih_l0"), eb, g("inter_rnn.bias_ih_l0"), g("inter_rnn.bias_hh_l0"))
+    gps = gate_prescale(64, intra_b.device)
+    out["intra_b16"] = (intra_b.double() * gps[None, :]).float()          # same row scale as the images (gate_prescale)
     out["inter_w16"] = pack_lstm_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
-    out["inter_b16"] = fold_b(g("inter_rnn.weight_ih_l0"), eb, g("inter_rnn.bias_ih_l0"), g("inter_rnn.bias_hh_l0"))
+    out["inter_b16"] = (inter_b.double() * gps).float()
     # streaming intra kernel (lh_stream.hip): gate columns in the order n = 32 w + 8 r + 4 u + g  <->  gate g of hidden
     # unit 8 w + 2 r + u (PyTorch row g*64 + unit); W_hh additionally split into the two k halves of thread 2n + kh
     n = torch.arange(256, device=iw.device)
     perm = (n & 3) * 64 + (n >> 5) * 8 + ((n >> 3) & 3) * 2 + ((n >> 2) & 1)
     out["intra_s_wih"] = torch.stack([pack_linear_f16x3(fold_w(g("intra_rnn.weight_ih_l0"), iw)[perm]),
                                       pack_linear_f16x3(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw)[perm])])
-    out["intra_s_b"] = out["intra_b16"][:, perm]
+    out["intra_s_b"] = intra_b[:, perm]
     out["intra_s_whh"] = torch.stack([g("intra_rnn.weight_hh_l0")[perm].reshape(512, 32),
                                       g("intra_rnn.weight_hh_l0_reverse")[perm].reshape(512, 32)])
     # the same layout for the per-sequence inter kernel (lh_inter_matvec, small batches)
     out["inter_s_wih"] = pack_linear_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew)[perm])
-    out["inter_s_b"] = out["inter_b16"][perm]
+    out["inter_s_b"] = inter_b[perm]
     out["inter_s_whh"] = g("inter_rnn.weight_hh_l0")[perm].reshape(512, 32)
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
     out["intra_lin_w"], out["intra_lin_b"] = pack_linear_f16x3(g("intra_linear.weight")), g("intra_linear.bias")
     # fused kernels: per-direction halves of the bidirectional projection [2 passes][4][2][64][2][8]
-    out["intra_lin_w2"] = torch.stack([pack_linear_f16x3(g("intra_linear.weight")[:, :64].contiguous()),
-                                       pack_linear_f16x3(g("intra_linear.weight")[:, 64:].contiguous())])
+    out["intra_lin_w2"] = torch.stack([pack_linear_f16x3(g("intra_linear.weight")[:, :64].contiguous(), unscaled=True),
+                                       pack_linear_f16x3(g("intra_linear.weight")[:, 64:].contiguous(), unscaled=True)])
     out["inter_ln_w"], out["inter_ln_b"] = g("inter_norm.norm.weight"), g("inter_norm.norm.bias")
     out["inter_w"] = pack_lstm(g("inter_rnn.weight_ih_l0"), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["inter_b"] = g("inter_rnn.bias_ih_l0") + g("inter_rnn.bias_hh_l0")
     out["inter_lin_w"], out["inter_lin_b"] = pack_linear_f16x3(g("inter_linear.weight")), g("inter_linear.bias")
+    out["inter_lin_wu"] = pack_linear_f16x3(g("inter_linear.weight"), unscaled=True)      # fused kernel (lh_inter_block)
     out["qkv_w"] = pack_linear_f16x3(torch.cat([g("attn_conv_Q.0.weight"), g("attn_conv_K.0.weight"),
                                                 g("attn_conv_V.0.weight")], 0))
     out["qkv_b"] = torch.cat([g("attn_conv_Q.0.bias"), g("attn_conv_K.0.bias"), g("attn_conv_V.0.bias")])

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "lookoncetohear_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "liblookonce_emu.so")
-SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_stream.hip"]
+SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_stream.hip", "lh_comm.hip"]
 
 
 def build_emu(force=False, extra_flags=(), out=OUT):
@@ -21,7 +21,7 @@ def build_emu(force=False, extra_flags=(), out=OUT):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-march=native", *extra_flags,
-           "-I", os.path.join(HERE, "include"), *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+           "-I", os.path.join(HERE, "include"), *[os.path.join(CSRC, s) for s in SOURCES], "-ldl", "-o", out]
     subprocess.check_call(cmd)
     return out
 

@@ -64,3 +64,14 @@ def test_dropin_surface():
         net.eval()(torch.zeros(1, 2, 1000), torch.zeros(1, 1, 256))
     with pytest.raises(NotImplementedError):
         Net()                                                           # reference defaults: unsupported shapes
+
+
+def test_exchange_entry_points_validate_arguments():
+    """lh_comm_* / lh_allreduce_f64 (the sharded eval's one exchange step for Python-free hosts): exported, and bad
+    arguments are refused before RCCL is touched (no GPU here, so no communicator is created)."""
+    from lookoncetohear_amd.build import build_hip
+    lib = _cabi.Lib(build_hip())
+    assert lib.raw("lh_comm_unique_id")(None) == 1                      # LH_ERR_ARG
+    assert lib.raw("lh_comm_init")(None, 2, 0, None) == 1
+    assert lib.raw("lh_allreduce_f64")(None, None, 4, None) == 1
+    assert lib.raw("lh_comm_destroy")(None) == 1

@@ -106,3 +106,18 @@ def test_foreign_filterbank_keys_are_dropped_and_training_forward_is_refused(ora
     net.load_state_dict(sd2, strict=True)
     with pytest.raises(RuntimeError, match="inference-only"):
         net(torch.zeros(1, 2, 1000), torch.zeros(1, 1, 256))
+
+
+def test_aten_port_reproduces_reference_fp32_goldens(golden, oracle_cfg_sd):
+    """oracle/aten_port.py issues the reference's own ATen operator sequence (it is what bench.py's cpu_baseline times):
+    against the reference's committed fp32 outputs it agrees to the last bits (bit-identical on the machine that wrote
+    the goldens: `python -m oracle.aten_port`; other CPUs may pick other MKL / oneDNN kernels, hence 1e-6)."""
+    from oracle import aten_port as P
+    _, sd = oracle_cfg_sd
+    d = P.Dims()
+    for name, idx, n in (("off_b2_n8000", [0, 1], 8000), ("off_b1_n8100", [2], 8100)):
+        b = synth.batch(idx, n)
+        y = P.forward(d, sd, b["mixture"], b["embedding_gt"])
+        assert y.shape == golden[name + "_y32"].shape
+        assert _maxabs(y, golden[name + "_y32"]) < 1e-6 * max(1.0, float(np.abs(golden[name + "_y32"]).max()))
+        assert _maxabs(y, golden[name + "_y64"]) < TOL32
