@@ -132,6 +132,11 @@ int lh_intra_block(const float* x, const void* w_pk, const float* b_sum, const v
 /* A.3.2 + Linear fused: LayerNorm -> causal LSTM over time (state in/out) -> Linear(64->64) -> + residual;
  * replaces tfgridnet_causal.py:521-538.   x, out [B][T][97][64]; wlin_pk [4][2][64][16] fp16 hi/lo (lo unscaled,
  * weights.py `inter_lin_wu`); blin [64]
+ *   w_pk   [8 waves][2 tiles][4 ksteps][64 lanes][hi 8 | lo 8] fp16 (weights.py pack_lstm_f16x3_w8, `inter_w8`): the
+ *          eight-wave kernel multiplies transposed (weights = MFMA A operand); lane l of (wave v, tile m, kstep ks)
+ *          holds row gate*64 + unit of [W_ih * ln_w | W_hh], gate = (l & 15) & 3, unit = 8v + 4m + ((l & 15) >> 2),
+ *          at k = 32 ks + 8 (l >> 4) + j; lo unscaled, rows scaled by the gate's exponent factor;
+ *   b_sum  [256] in PyTorch gate order (i, f, g, o) x 64, same scaling (weights.py `inter_b16`)
  */
 int lh_inter_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                    const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,

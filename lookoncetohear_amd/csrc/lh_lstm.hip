@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     __syncthreads();
 
     // one step; CUR = A / projection buffer of this step (compile-time: the loop below is unrolled by two)
-    auto step = [&](int it, auto cur_tag) {
+    auto step = [&](int it, auto cur_tag) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
         // Everything that CONSUMES global loads (x of step it+1 and the projection base of step it-2, both fetched one
         // step ago) comes first, the step's own global traffic after it: the wave then waits once, at the top, for
@@ -684,6 +684,237 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
                 const int s = s0 + m * 16 + g4 * 4 + r;
                 if (s < nseq) cN[(long)s * H + unit] = creg[m][r];
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Eight-wave variant of the fused recurrence for the LATENCY-bound regime (the inter pass: 625 dependent steps and, at
+// batch 32, only 194 sixteen-sequence tiles for 256 CUs, i.e. one workgroup per CU and — with four waves — one wave per
+// SIMD that serialises its own LDS / MFMA / transcendental latencies: 1.14 us per step against 0.8 us of issue time).
+// Same tile (16 sequences, all steps), same LDS images, but 512 threads: two waves per SIMD that cover each other's
+// stalls.  Wave v owns hidden units 8v..8v+7 of all four gates; the gate GEMM is TRANSPOSED (weights are the MFMA A
+// operand, activations the B operand) so that the accumulator tile is [16 gate columns] x [16 sequences] with rows
+// ordered (unit, gate): a lane then holds the four gates of ONE unit of ONE sequence in the four registers of a tile
+// and the cell update stays lane-local with two cells per lane.  Waves 0..3 also run the output projection of
+// h_{t-1} (their B fragments of the h half double as its A operand) and finish / fetch the output rows; waves 4..7
+// normalise and split x_{t+1}.  Each SIMD hosts one wave of either kind.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 1) k_lstm_lin8(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
+                                                      const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
+                                                      const float* __restrict__ blin, const float* __restrict__ h0,
+                                                      const float* __restrict__ c0, float* __restrict__ hN,
+                                                      float* __restrict__ cN, float* out, int nseq, int nstep, int sdiv,
+                                                      int so, int si, int ps, int dir, int accumulate) {
+    constexpr int NS = 16;
+    constexpr int LSP = C + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
+    __shared__ __attribute__((aligned(16))) float ls[2 * NS * LSP];
+    __shared__ __attribute__((aligned(16))) float hf[NS * LSP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the role branches below are s_cbranch
+    const int s0 = blockIdx.x * NS;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const bool lin_wave = wave < 4;                  // wave-uniform role
+    const int q = tid & 15, rrow = (tid & 255) >> 4; // row-wise roles: float4 q of row rrow
+    const int unit0 = 8 * wave + g4;                 // this lane's cells: units unit0 and unit0 + 4 of sequence l15
+
+    auto row_of0 = [&](int s) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si; };
+    const long wg_row0 = row_of0(min(s0, nseq - 1));
+    const unsigned voff = (unsigned)((row_of0(min(s0 + rrow, nseq - 1)) - wg_row0) * (C * 4) + q * 16);
+    const char* xb = reinterpret_cast<const char*>(x) + wg_row0 * (C * 4);
+    char* ob = reinterpret_cast<char*>(out) + wg_row0 * (C * 4);
+    // base of the projection rows: pass 0 the residual x, an accumulating pass the partial sums already in `out`
+    // (integer select: a select between two pointers is lowered to a table in scratch memory)
+    const char* bsrc = reinterpret_cast<const char*>(
+        accumulate ? reinterpret_cast<unsigned long long>(ob) : reinterpret_cast<unsigned long long>(xb));
+    const long step_bytes = (long)ps * (C * 4);
+    auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
+
+    // resident weights: A-operand fragments [tile][kstep] of this wave's 32 gate columns (image: weights.py
+    // pack_lstm_f16x3_w8), the projection's B fragments (waves 0..3), biases of the lane's two units
+    f16x8 wh[2][4], wl[2][4];
+    {
+        const _Float16* wp = w_pk + ((long)(dir * 8 + wave) * 8 * 64 + lane) * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wh[m][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(m * 4 + ks) * 64 * 16);
+                wl[m][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(m * 4 + ks) * 64 * 16 + 8);
+            }
+    }
+    f16x8 lwh[2], lwl[2];
+    float lbias = 0.0f;
+    if (lin_wave) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            lwh[ks] = *reinterpret_cast<const f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16]);
+            lwl[ks] = *reinterpret_cast<const f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16 + 8]);
+        }
+        if (!accumulate) lbias = blin[wave * 16 + l15];
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) lwh[ks] = lwl[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float bias[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[m][g] = b_sum[dir * 256 + g * 64 + unit0 + 4 * m];
+
+    const int a_frag = l15 * LH_AP + g4 * 8;         // B operand of the gate GEMM / A operand of the projection
+    const int a_cell = l15 * LH_AP + C + unit0;      // where this lane's h values go (+ 4 m)
+    const int a_row = rrow * LH_AP + q * 4;
+    const int l_row = rrow * LSP + q * 4;
+    const int l_lin = (g4 * 4) * LSP + wave * 16 + l15;
+
+    auto store_split4 = [&](int idx, float a, float b, float c, float d) {
+        f16x4 h4, l4;
+        _Float16 th, tl;
+        split_f16(a, th, tl); h4[0] = th; l4[0] = tl;
+        split_f16(b, th, tl); h4[1] = th; l4[1] = tl;
+        split_f16(c, th, tl); h4[2] = th; l4[2] = tl;
+        split_f16(d, th, tl); h4[3] = th; l4[3] = tl;
+        *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
+        *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
+    };
+    auto norm_store_x = [&](int buf, float4 v) {
+        const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+        const float rstd = __builtin_amdgcn_rsqf(var + LN_EPS);
+        store_split4(buf * NS * LH_AP + a_row, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
+    };
+    auto load_row = [&](const char* base, int it) -> float4 {
+        return *reinterpret_cast<const float4*>(base + step_pos(it) * step_bytes + voff);
+    };
+
+    // ---- prologue
+    float creg[2], hreg[2];
+    // the one global row a thread carries from step to step: waves 4..7 x_{it+1} (fetched a step ahead), waves 0..3 the
+    // base of the projection rows of step it-2
+    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!lin_wave) {
+        norm_store_x(0, load_row(xb, 0));
+        carry = load_row(xb, 1);
+    } else {
+        const int s = min(s0 + rrow, nseq - 1);
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
+        store_split4(a_row + C, hv.x, hv.y, hv.z, hv.w);
+    }
+    {
+        const int s = min(s0 + l15, nseq - 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            creg[m] = c0 ? c0[(long)s * H + unit0 + 4 * m] : 0.0f;
+            hreg[m] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    auto step = [&](int it, auto cur_tag) __attribute__((always_inline)) {
+        constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+        // row-wise roles first: consumers of the global loads issued one step ago, then this step's own global traffic
+        pin_here(carry);
+        if (lin_wave) {
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * LSP + l_row]);
+            const float4 done = make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it >= 2) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done;
+            carry = load_row(bsrc, it - 1);
+        } else {
+            norm_store_x(nxt, carry);
+            __builtin_amdgcn_sched_barrier(0);
+            carry = load_row(xb, it + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x4 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m] = f32x4{bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+        f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bh[ks] = *reinterpret_cast<const f16x8*>(&ahi[cur * NS * LH_AP + a_frag + ks * 32]);
+            bl[ks] = *reinterpret_cast<const f16x8*>(&alo[cur * NS * LH_AP + a_frag + ks * 32]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][ks], bh[ks], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][ks], bl[ks], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[m][ks], bh[ks], acc[m], 0, 0, 0);
+        }
+        if (lin_wave) {                               // projection of h_{it-1}: rows = sequences, this wave's 16 output columns
+            f32x4 am = f32x4{lbias, lbias, lbias, lbias};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[2 + ks], lwh[ks], am, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[2 + ks], lwl[ks], am, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[2 + ks], lwh[ks], am, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ls[cur * NS * LSP + r * LSP + l_lin] = am[r];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            lstm_cell_pre(acc[m][0], acc[m][1], acc[m][2], acc[m][3], creg[m], hreg[m]);
+            _Float16 th, tl;
+            split_f16(hreg[m], th, tl);
+            ahi[nxt * NS * LH_AP + a_cell + 4 * m] = th;
+            alo[nxt * NS * LH_AP + a_cell + 4 * m] = tl;
+        }
+        __syncthreads();
+    };
+    {
+        int it = 0;
+        for (; it + 1 < nstep; it += 2) {
+            step(it, std::integral_constant<int, 0>{});
+            step(it + 1, std::integral_constant<int, 1>{});
+        }
+        if (it < nstep) step(it, std::integral_constant<int, 0>{});
+    }
+
+    // ---- drain: rows of the last two steps (projection of h_{nstep-1} still to do)
+    const int lastb = nstep & 1;
+    if (lin_wave) {
+        if (nstep >= 2) {
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[(lastb ^ 1) * NS * LSP + l_row]);
+            *reinterpret_cast<float4*>(ob + step_pos(nstep - 2) * step_bytes + voff) =
+                make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+        }
+        carry = load_row(bsrc, nstep - 1);
+        f32x4 am = f32x4{lbias, lbias, lbias, lbias};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[lastb * NS * LH_AP + a_frag + (2 + ks) * 32]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[lastb * NS * LH_AP + a_frag + (2 + ks) * 32]);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwh[ks], am, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwl[ks], am, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, lwh[ks], am, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ls[lastb * NS * LSP + r * LSP + l_lin] = am[r];
+    }
+    if (hN) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) hf[l15 * LSP + unit0 + 4 * m] = hreg[m];
+    }
+    __syncthreads();
+    if (lin_wave) {
+        const float4 pv = *reinterpret_cast<const float4*>(&ls[lastb * NS * LSP + l_row]);
+        *reinterpret_cast<float4*>(ob + step_pos(nstep - 1) * step_bytes + voff) =
+            make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+    } else if (hN && s0 + rrow < nseq) {
+        *reinterpret_cast<float4*>(&hN[(long)(s0 + rrow) * H + q * 4]) = *reinterpret_cast<const float4*>(&hf[l_row]);
+    }
+    if (cN && s0 + l15 < nseq) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + 4 * m] = creg[m];
     }
 }
 
@@ -829,6 +1060,10 @@ extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_s
     using namespace lh;
     if (!x || !w_pk || !b_sum || !wlin_pk || !blin || !h0 || !c0 || !hN || !cN || !out || B <= 0 || T <= 0) return LH_ERR_ARG;
     if (h0 == hN || c0 == cN || x == out) return LH_ERR_ARG;
-    return launch_lstm_lin<1>(x, w_pk, b_sum, wlin_pk, blin, h0, c0, hN, cN, out, B * NF, T, NF, T * NF, 1, NF, 0, 0,
-                              (hipStream_t)stream);
+    // sequence s = b*97 + f; step = frame t; row(s, t) = (b*T + t)*97 + f.  Eight-wave tiles (k_lstm_lin8): the pass is a
+    // 625-step dependent chain, two waves per SIMD cover each other's latencies
+    const int nseq = B * NF;
+    hipLaunchKernelGGL(k_lstm_lin8, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,
+                       b_sum, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF, 0, 0);
+    return check_launch();
 }

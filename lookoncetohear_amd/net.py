@@ -384,7 +384,7 @@ class Net(nn.Module):
                     lib.call("lh_inter_matvec", P(xb), P(bp["inter_s_wih"]), P(bp["inter_s_b"]), P(bp["inter_s_whh"]),
                              P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
                 elif fuse:
-                    lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
+                    lib.call("lh_inter_block", P(xb), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
                              P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(xc), Bn, T, st)
                 else:
                     # inter: LN + causal LSTM over time with carried state -> Linear(64->64) + residual
@@ -466,7 +466,7 @@ class Net(nn.Module):
                      Bn * T, st)
             lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), Bn * T * F_,
                      2 * H_, st)
-            lib.call("lh_inter_block", P(xb), P(bp["inter_w16"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
+            lib.call("lh_inter_block", P(xb), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
                      P(bp["inter_lin_b"]), P(sin["h"][i]), P(sin["c"][i]), P(sout["h"][i]), P(sout["c"][i]), P(xc), Bn, T, st)
             lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
                      P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
@@ -571,7 +571,10 @@ class Streamer:
 
     def step(self, chunk: torch.Tensor) -> torch.Tensor:
         """chunk [B, 2, 192] (128 new + 64 look-ahead samples) -> [B, 2, 128]."""
-        if self.net._weights(self.device) is not self._pk:
+        # O(1) staleness check (re-deriving the pack key walks all 130 parameters: ~0.1 ms of host time per 8 ms chunk):
+        # any `Net` call after a parameter change re-packs and replaces `net._packed`.  The streamer owns references to
+        # the images its graphs point into, so a stale streamer is never unsafe, only out of date.
+        if self.net._packed is not self._pk:
             raise RuntimeError("the Net's parameters changed after this Streamer was built (its HIP graphs hold pointers "
                                "into the old packed weights): create a new streamer with net.make_streamer(...)")
         self.chunk.copy_(chunk)

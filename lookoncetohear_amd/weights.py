@@ -110,6 +110,29 @@ def pack_lstm_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo], dim=4).contiguous()             # [4,4,4,64,2,8]
 
 
+def pack_lstm_f16x3_w8(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """Image of the eight-wave fused kernel (lh_lstm.hip k_lstm_lin8), where the weights are the MFMA **A** operand of a
+    transposed gate GEMM: [8 waves, 2 tiles, 4 ksteps, 64 lanes, 2 (hi|lo), 8] fp16, lo unscaled, rows pre-scaled by
+    `gate_prescale`.  Lane l of (wave v, tile m, k-step ks) holds row  gate*64 + unit  of [W_ih | W_hh] with
+    gate = (l & 15) & 3, unit = 8v + 4m + ((l & 15) >> 2), at k = ks*32 + (l >> 4)*8 + j: the accumulator tile is then
+    [16 rows = (unit, gate)] x [16 sequences] and a lane's four registers are the four gates of one unit."""
+    H = w_hh.shape[1]
+    assert H == 64 and tuple(w_ih.shape) == (4 * H, 64)
+    wcat = torch.cat([w_ih, w_hh], dim=1).double()
+    wcat = (wcat * gate_prescale(H, wcat.device)[:, None]).float()
+    dev = wcat.device
+    lane = torch.arange(64, device=dev)
+    wave = torch.arange(8, device=dev)[:, None, None, None, None]
+    tile = torch.arange(2, device=dev)[None, :, None, None, None]
+    ks = torch.arange(4, device=dev)[None, None, :, None, None]
+    j = torch.arange(8, device=dev)[None, None, None, None, :]
+    rho = (lane & 15)[None, None, None, :, None]
+    row = (rho & 3) * H + wave * 8 + tile * 4 + (rho >> 2)
+    k = ks * 32 + (lane >> 4)[None, None, None, :, None] * 8 + j
+    hi, lo = split_f16_unscaled(wcat[row, k])
+    return torch.stack([hi, lo], dim=4).contiguous()             # [8,2,4,64,2,8]
+
+
 def pack_linear_f16x3(w: torch.Tensor, unscaled: bool = False) -> torch.Tensor:
     """w [N, K] -> split-precision B image [N/16, K/32, 64 lanes, 2 (hi|lo), 8] fp16 for v_mfma_f32_16x16x32_f16:
     lane l of (n-tile nt, k-step ks) holds W[nt*16 + (l & 15)][ks*32 + (l >> 4)*8 + j], j = 0..7.
@@ -150,6 +173,7 @@ def pack_block(sd: dict, pre: str) -> dict:
     out["intra_b16"] = (intra_b.double() * gps[None, :]).float()          # same row scale as the images (gate_prescale)
     out["inter_w16"] = pack_lstm_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["inter_b16"] = (inter_b.double() * gps).float()
+    out["inter_w8"] = pack_lstm_f16x3_w8(fold_w(g("inter_rnn.weight_ih_l0"), ew), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     # streaming intra kernel (lh_stream.hip): gate columns in the order n = 32 w + 8 r + 4 u + g  <->  gate g of hidden
     # unit 8 w + 2 r + u (PyTorch row g*64 + unit); W_hh additionally split into the two k halves of thread 2n + kh
     n = torch.arange(256, device=iw.device)
