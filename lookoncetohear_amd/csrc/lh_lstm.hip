@@ -918,6 +918,269 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Software-pipelined eight-wave recurrence (k_lstm_lin8p).  Same tile, roles, weight image and LDS rows as k_lstm_lin8,
+// but the NON-recurrent half of the gate GEMM — LN(x_{t+1}) W_ih'^T + b, K = 64 of the 128 — leaves the dependent chain:
+// it is computed during step t, after the recurrent half of step t has been issued, so its 12 MFMAs per wave (plus the
+// 6 of the output projection on waves 0..3) run in the matrix pipe underneath the transcendental-heavy cell update of
+// step t (MFMA and VALU of one SIMD overlap: an MFMA holds the vector issue port for ~8 of its ~19 cycles,
+// profiles/r02a_ubench_issue_model.txt).  The chain of a step is then
+//     barrier -> ds_read h -> 12 MFMA (K = 64, accumulators start from the pre-computed x half) -> cells -> ds_write h
+// instead of 24 (+6) MFMAs ahead of the cells.  The x half of the LDS rows runs one step further ahead than the h
+// half: during step t buffer (t & 1) receives x_{t+2} (its x_t was consumed in step t-1) while x_{t+1} is read from
+// buffer (t+1) & 1; the h halves alternate as before.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
+                                                       const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
+                                                       const float* __restrict__ blin, const float* __restrict__ h0,
+                                                       const float* __restrict__ c0, float* __restrict__ hN,
+                                                       float* __restrict__ cN, float* out, int nseq, int nstep, int sdiv,
+                                                       int so, int si, int ps, int dir, int accumulate) {
+    constexpr int NS = 16;
+    constexpr int LSP = C + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
+    __shared__ __attribute__((aligned(16))) float ls[2 * NS * LSP];
+    __shared__ __attribute__((aligned(16))) float hf[NS * LSP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s0 = blockIdx.x * NS;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const bool lin_wave = wave < 4;
+    const int q = tid & 15, rrow = (tid & 255) >> 4;
+    const int unit0 = 8 * wave + g4;
+
+    auto row_of0 = [&](int s) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si; };
+    const long wg_row0 = row_of0(min(s0, nseq - 1));
+    const unsigned voff = (unsigned)((row_of0(min(s0 + rrow, nseq - 1)) - wg_row0) * (C * 4) + q * 16);
+    const char* xb = reinterpret_cast<const char*>(x) + wg_row0 * (C * 4);
+    char* ob = reinterpret_cast<char*>(out) + wg_row0 * (C * 4);
+    const char* bsrc = reinterpret_cast<const char*>(
+        accumulate ? reinterpret_cast<unsigned long long>(ob) : reinterpret_cast<unsigned long long>(xb));
+    const long step_bytes = (long)ps * (C * 4);
+    auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
+
+    f16x8 wh[2][4], wl[2][4];
+    {
+        const _Float16* wp = w_pk + ((long)(dir * 8 + wave) * 8 * 64 + lane) * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wh[m][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(m * 4 + ks) * 64 * 16);
+                wl[m][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(m * 4 + ks) * 64 * 16 + 8);
+            }
+    }
+    f16x8 lwh[2], lwl[2];
+    float lbias = 0.0f;
+    if (lin_wave) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            lwh[ks] = *reinterpret_cast<const f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16]);
+            lwl[ks] = *reinterpret_cast<const f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16 + 8]);
+        }
+        if (!accumulate) lbias = blin[wave * 16 + l15];
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) lwh[ks] = lwl[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float bias[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[m][g] = b_sum[dir * 256 + g * 64 + unit0 + 4 * m];
+
+    const int a_frag = l15 * LH_AP + g4 * 8;
+    const int a_cell = l15 * LH_AP + C + unit0;
+    const int a_row = rrow * LH_AP + q * 4;
+    const int l_row = rrow * LSP + q * 4;
+    const int l_lin = (g4 * 4) * LSP + wave * 16 + l15;
+
+    auto store_split4 = [&](int idx, float a, float b, float c, float d) {
+        f16x4 h4, l4;
+        _Float16 th, tl;
+        split_f16(a, th, tl); h4[0] = th; l4[0] = tl;
+        split_f16(b, th, tl); h4[1] = th; l4[1] = tl;
+        split_f16(c, th, tl); h4[2] = th; l4[2] = tl;
+        split_f16(d, th, tl); h4[3] = th; l4[3] = tl;
+        *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
+        *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
+    };
+    auto norm_store_x = [&](int buf, float4 v) {
+        const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+        const float rstd = __builtin_amdgcn_rsqf(var + LN_EPS);
+        store_split4(buf * NS * LH_AP + a_row, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
+    };
+    auto load_row = [&](const char* base, int it) -> float4 {
+        return *reinterpret_cast<const float4*>(base + step_pos(it) * step_bytes + voff);
+    };
+    // x half of one step's gates: bias + LN(x) W_ih'^T from the x fragments (k-steps 0, 1) of A buffer `buf`
+    auto x_half = [&](int buf, f32x4 (&g)[2]) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) g[m] = f32x4{bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 xh = *reinterpret_cast<const f16x8*>(&ahi[buf * NS * LH_AP + a_frag + ks * 32]);
+            const f16x8 xl = *reinterpret_cast<const f16x8*>(&alo[buf * NS * LH_AP + a_frag + ks * 32]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) g[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][ks], xh, g[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) g[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][ks], xl, g[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) g[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[m][ks], xh, g[m], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: x_0, x_1 normalised into the two buffers, x_2 in flight; h_{-1}; x half of step 0
+    float creg[2], hreg[2];
+    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!lin_wave) {
+        norm_store_x(0, load_row(xb, 0));
+        norm_store_x(1, load_row(xb, 1));
+        carry = load_row(xb, 2);
+    } else {
+        const int s = min(s0 + rrow, nseq - 1);
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
+        store_split4(a_row + C, hv.x, hv.y, hv.z, hv.w);
+    }
+    {
+        const int s = min(s0 + l15, nseq - 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            creg[m] = c0 ? c0[(long)s * H + unit0 + 4 * m] : 0.0f;
+            hreg[m] = 0.0f;
+        }
+    }
+    __syncthreads();
+    f32x4 gx[2];
+    x_half(0, gx);
+    __syncthreads();                                  // buffer 0's x half is rewritten (x_2) in step 0
+
+    // One step, specialised on the wave's role (LIN: waves 0..3) and on the buffer parity, as ONE basic block behind the
+    // row-wise prologue so that the scheduler can be told to interleave the off-chain MFMAs with the cell update.
+    auto step = [&](int it, auto cur_tag, auto lin_tag) __attribute__((always_inline)) {
+        constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+        constexpr bool LIN = decltype(lin_tag)::value;
+        pin_here(carry);
+        if (LIN) {
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * LSP + l_row]);
+            const float4 done = make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it >= 2) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done;
+            carry = load_row(bsrc, it - 1);
+        } else {
+            norm_store_x(cur, carry);                 // x_{it+2}
+            __builtin_amdgcn_sched_barrier(0);
+            carry = load_row(xb, it + 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // recurrent half: acc = (x half of this step, computed a step ago) + h_{it-1} W_hh^T
+        f16x8 bh[2], bl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bh[ks] = *reinterpret_cast<const f16x8*>(&ahi[cur * NS * LH_AP + a_frag + (2 + ks) * 32]);
+            bl[ks] = *reinterpret_cast<const f16x8*>(&alo[cur * NS * LH_AP + a_frag + (2 + ks) * 32]);
+        }
+        f32x4 acc[2] = {gx[0], gx[1]};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][2 + ks], bh[ks], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][2 + ks], bl[ks], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[m][2 + ks], bh[ks], acc[m], 0, 0, 0);
+        }
+        // Off the chain: x half of step it+1 (buffer nxt holds x_{it+1}) and, on waves 0..3, the projection of h_{it-1}.
+        // The two waves of a SIMD take opposite orders: the LIN wave issues its 18 off-chain MFMAs first and updates its
+        // cells afterwards, the other wave updates its cells first — one wave's transcendentals run under the other's
+        // matrix work (in-order issue inside a wave would otherwise queue the cells behind both waves' MFMAs).
+        auto cells = [&]() {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                lstm_cell_pre(acc[m][0], acc[m][1], acc[m][2], acc[m][3], creg[m], hreg[m]);
+                _Float16 th, tl;
+                split_f16(hreg[m], th, tl);
+                ahi[nxt * NS * LH_AP + a_cell + 4 * m] = th;
+                alo[nxt * NS * LH_AP + a_cell + 4 * m] = tl;
+            }
+        };
+        if (LIN) {
+            x_half(nxt, gx);
+            f32x4 am = f32x4{lbias, lbias, lbias, lbias};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks], lwh[ks], am, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks], lwl[ks], am, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ks], lwh[ks], am, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cells();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ls[cur * NS * LSP + r * LSP + l_lin] = am[r];
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            cells();
+            __builtin_amdgcn_sched_barrier(0);
+            x_half(nxt, gx);
+        }
+        __builtin_amdgcn_sched_barrier(0);            // keep the off-chain MFMAs on this side of the barrier
+        __syncthreads();
+    };
+    auto run = [&](auto lin_tag) __attribute__((always_inline)) {
+        int it = 0;
+        for (; it + 1 < nstep; it += 2) {
+            step(it, std::integral_constant<int, 0>{}, lin_tag);
+            step(it + 1, std::integral_constant<int, 1>{}, lin_tag);
+        }
+        if (it < nstep) step(it, std::integral_constant<int, 0>{}, lin_tag);
+    };
+    if (lin_wave) run(std::true_type{});
+    else run(std::false_type{});
+
+    // ---- drain (as k_lstm_lin8)
+    const int lastb = nstep & 1;
+    if (lin_wave) {
+        if (nstep >= 2) {
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[(lastb ^ 1) * NS * LSP + l_row]);
+            *reinterpret_cast<float4*>(ob + step_pos(nstep - 2) * step_bytes + voff) =
+                make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+        }
+        carry = load_row(bsrc, nstep - 1);
+        f32x4 am = f32x4{lbias, lbias, lbias, lbias};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[lastb * NS * LH_AP + a_frag + (2 + ks) * 32]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[lastb * NS * LH_AP + a_frag + (2 + ks) * 32]);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwh[ks], am, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwl[ks], am, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, lwh[ks], am, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ls[lastb * NS * LSP + r * LSP + l_lin] = am[r];
+    }
+    if (hN) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) hf[l15 * LSP + unit0 + 4 * m] = hreg[m];
+    }
+    __syncthreads();
+    if (lin_wave) {
+        const float4 pv = *reinterpret_cast<const float4*>(&ls[lastb * NS * LSP + l_row]);
+        *reinterpret_cast<float4*>(ob + step_pos(nstep - 1) * step_bytes + voff) =
+            make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+    } else if (hN && s0 + rrow < nseq) {
+        *reinterpret_cast<float4*>(&hN[(long)(s0 + rrow) * H + q * 4]) = *reinterpret_cast<const float4*>(&hf[l_row]);
+    }
+    if (cN && s0 + l15 < nseq) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + 4 * m] = creg[m];
+    }
+}
+
 static int g_dephase = 1;          // lh_set_tuning(3, 0) switches the slot-parity issue priority off (A/B runs)
 template <int MT>
 static int launch_lstm_lin(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
@@ -1063,7 +1326,11 @@ extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_s
     // sequence s = b*97 + f; step = frame t; row(s, t) = (b*T + t)*97 + f.  Eight-wave tiles (k_lstm_lin8): the pass is a
     // 625-step dependent chain, two waves per SIMD cover each other's latencies
     const int nseq = B * NF;
-    hipLaunchKernelGGL(k_lstm_lin8, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,
-                       b_sum, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF, 0, 0);
+    if (g_tune[2] == 1)      // A/B: the un-pipelined eight-wave kernel
+        hipLaunchKernelGGL(k_lstm_lin8, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,
+                           b_sum, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF, 0, 0);
+    else
+        hipLaunchKernelGGL(k_lstm_lin8p, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,
+                           b_sum, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF, 0, 0);
     return check_launch();
 }

@@ -29,8 +29,8 @@ def main(fetch_csv, write_csv, batch, out_json):
     wg = lambda nseq: ((nseq + 15) // 16) * 256          # LSTM launches: 16 sequences per 256-thread workgroup
     # C-ABI call -> (kernel-name substring, grid size or None, algorithmic bytes per kernel launch)
     table = {
-        "lh_intra_block": ("k_ln_lstm_lin", wg(B * T), 2.5 * A),
-        "lh_inter_block": ("k_ln_lstm_lin", wg(B * F), 2.0 * A),
+        "lh_intra_block": (("k_ln_lstm_lin", "k_lstm_pp"), None, 2.5 * A),
+        "lh_inter_block": ("k_lstm_lin8", None, 2.0 * A),
         "lh_qkv_proj_ln": ("k_qkv_proj_ln", None, 2 * A + 2 * qk),
         "lh_local_attn": ("k_local_attn", None, 2 * qk + 2 * A),
         "lh_proj_ln_res": ("k_proj_ln_res", None, 3 * A),
@@ -39,8 +39,10 @@ def main(fetch_csv, write_csv, batch, out_json):
     }
     kernels = {}
     for call, (pat, grid, alg) in table.items():
-        f = [(k, v) for k, v in fe.items() if pat in k[0] and (grid is None or k[1] == grid)]
-        w = [(k, v) for k, v in wr.items() if pat in k[0] and (grid is None or k[1] == grid)]
+        pats = (pat,) if isinstance(pat, str) else pat
+        hit = lambda k: any(q in k[0] for q in pats) and (grid is None or k[1] == grid)
+        f = [(k, v) for k, v in fe.items() if hit(k)]
+        w = [(k, v) for k, v in wr.items() if hit(k)]
         if not f or not w:
             continue
         fn = sum(v[0] for _, v in f); wn = sum(v[0] for _, v in w)
