@@ -60,6 +60,26 @@ __device__ __forceinline__ void lstm_cell(float gi, float gf, float gg, float go
 // carry the exponent scale (rows i, f, o times -log2 e, rows g times -2 log2 e: weights.py GATE_PRESCALE), so
 // sigma = rcp(1 + exp2(a)) and tanh = 2 rcp(1 + exp2(a)) - 1 need no multiply on the way in (16 VALU per step).
 __device__ __forceinline__ void lstm_cell_pre(float ai, float af, float ag, float ao, float& c, float& h) {
+#if defined(LH_PROBE_NOTRANS)      // timing probe only (wrong results): no transcendentals at all
+    {
+        const float ig = 0.5f + 0.25f * ai, fg = 0.5f + 0.25f * af, g2 = 0.5f * ag, og = 0.5f + 0.25f * ao;
+        const float cc0 = fg * c + ig * g2;
+        c = cc0;
+        h = og * (0.5f * cc0);
+        return;
+    }
+#elif defined(LH_PROBE_NOTANHC)    // timing probe only: h = o * c (two transcendentals fewer)
+    {
+        const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ai));
+        const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(af));
+        const float g2 = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ag)) - 1.0f;
+        const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ao));
+        const float cc0 = fg * c + ig * g2;
+        c = cc0;
+        h = og * cc0;
+        return;
+    }
+#endif
     const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ai));
     const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(af));
     const float g2 = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ag)) - 1.0f;

@@ -201,6 +201,9 @@ __global__ void __launch_bounds__(256) k_ln_lstm(const float* __restrict__ x, co
 // weights resident in VGPRs (now as hi/lo fp16 fragments, same 128 registers), A = [LN(x_t) | h_{t-1}] staged
 // in LDS as fp16 hi/lo rows, one barrier per step.
 // ------------------------------------------------------------------------------------------------------
+#if defined(LH_PROBE_TRACE)        // timing probe build only: per-step s_memtime stamps of two workgroups of k_ln_lstm_lin
+__device__ unsigned long long lh_trace_buf[2 * 128 * 4];
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int LH_AP = 144;      // fp16 elements per LDS row: 128 + 16 pad (288 B: conflict-free ds_read_b128)
@@ -417,6 +420,14 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
     __shared__ __attribute__((aligned(16))) float ls[2 * NS * LSP];
     __shared__ __attribute__((aligned(16))) float hf[NS * LSP];                   // fp32 copy of the final hidden state
+#if defined(LH_PROBE_TRACE)
+    __shared__ unsigned long long tr[128 * 4];
+    const int tr_slot = blockIdx.x == 7 ? 0 : (blockIdx.x == gridDim.x - 9 ? 1 : -1);
+    const bool tr_on = tr_slot >= 0 && threadIdx.x == 0 && dir == 0;
+#define LH_STAMP(k) do { if (tr_on) tr[(it & 127) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LH_STAMP(k) do { } while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s0 = blockIdx.x * NS;
     const int g4 = lane >> 4, l15 = lane & 15;
@@ -546,7 +557,7 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     };
 
     // ---- prologue
-    float creg[MT][4], hreg[MT][4];                  // cell state; newest hidden state in fp32 (for the carried state)
+    float creg[MT][4];                               // cell state
     float4 xr[MT], rr[MT];
     {
         load_x(0, xr);
@@ -573,78 +584,115 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     // one step; CUR = A / projection buffer of this step (compile-time: the loop below is unrolled by two)
     auto step = [&](int it, auto cur_tag) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
-        // Everything that CONSUMES global loads (x of step it+1 and the projection base of step it-2, both fetched one
-        // step ago) comes first, the step's own global traffic after it: the wave then waits once, at the top, for
-        // accesses issued a whole step earlier.  (With the store scheduled ahead of the x consumer the compiler has to
-        // wait for vmcnt(0) right behind the store, i.e. for the write acknowledge, every step: +20 % on the intra pass.)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {                // (also keeps the unrolled twin's consumers behind its barrier)
-            pin_here(xr[i]);
-            pin_here(rr[i]);
-        }
-        norm_store_x(nxt, xr);
-        float4 done[MT];                              // rows of step it-2: projection parked in ls[nxt] one step ago
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const float4 pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * LSP + l_row[i]]);
-            done[i] = make_float4(rr[i].x + pv.x, rr[i].y + pv.y, rr[i].z + pv.z, rr[i].w + pv.w);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (it >= 2) {
-            char* base = ob + step_pos(it - 2) * step_bytes;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) *reinterpret_cast<float4*>(base + voff[i]) = done[i];
-        }
-        load_base(it - 1, rr);                        // consumed next iteration (clamped at it = 0: unused)
-        load_x(it + 2, xr);
-        __builtin_amdgcn_sched_barrier(0);
-
+        LH_STAMP(0);
+        // The row-wise work of the step (x_{it+1} normalised and split into the free buffer, rows of step it-2 finished
+        // and stored, the next rows fetched) is independent of the step's MFMAs, and a wave is strictly in-order: placed
+        // in front of the MFMAs it costs ~640 cycles of a ~2900-cycle step (s_memtime trace, profiles/r02d_*), placed
+        // BETWEEN them it issues in the matrix pipe's shadow (an MFMA keeps the pipe busy ~19 cycles and the issue port
+        // ~12).  Four groups of 12 MFMAs (one k-step each), each with a slice of the row work; the fences between the
+        // groups keep the memory operations in the order  consumers of last step's loads -> store -> new loads  so that
+        // the wave never waits for a store acknowledge.
         f32x4 gate[MT][4];
+        f16x8 fah[MT][4], fal[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) gate[m][g] = f32x4{bias[g], bias[g], bias[g], bias[g]};
-            const int ro = (cur * NS + m * 16) * LH_AP + a_frag;
-#ifdef LH_LSTM_ACC2        // A/B variant: the two small products in a second accumulator chain (8 chains of depth 4 / 8)
-            f32x4 accc[4];
+        }
+        auto read_frag = [&](int ks) __attribute__((always_inline)) {     // fragments are fetched two k-steps ahead of their MFMAs
 #pragma unroll
-            for (int g = 0; g < 4; ++g) accc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
+            for (int m = 0; m < MT; ++m) {
+                const int ro = (cur * NS + m * 16) * LH_AP + a_frag;
+                fah[m][ks] = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
+                fal[m][ks] = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
+            }
+        };
+        read_frag(0);
+        read_frag(1);
+        auto mfma_ks = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[ro + ks * 32]);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[ro + ks * 32]);
+            for (int m = 0; m < MT; ++m) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g][ks], gate[m][g], 0, 0, 0);
-#ifdef LH_LSTM_ACC2
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[m][ks], wh[g][ks], gate[m][g], 0, 0, 0);
+#if !defined(LH_PROBE_HIHI)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], accc[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[m][ks], wl[g][ks], gate[m][g], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) accc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], accc[g], 0, 0, 0);
-#else
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g][ks], gate[m][g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g][ks], gate[m][g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) gate[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal[m][ks], wh[g][ks], gate[m][g], 0, 0, 0);
 #endif
             }
-#ifdef LH_LSTM_ACC2
+        };
+        // group 0: k-step 0  +  x_{it+1}: statistics
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gate[m][g] += accc[g];
-#endif
+        for (int i = 0; i < MT; ++i) pin_here(xr[i]);     // (keeps the unrolled twin's consumers behind its barrier)
+        mfma_ks(0);
+        read_frag(2);
+        float4 xc[MT];
+        float rstd[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float4 v = xr[i];
+            const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+            v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+            const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+            rstd[i] = __builtin_amdgcn_rsqf(var + LN_EPS);      // var + eps >= 1e-5: no denormal guard needed
+            xc[i] = v;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // group 1: k-step 1  +  x_{it+1} split into the free buffer, rows of step it-2 summed up
+        mfma_ks(1);
+        read_frag(3);
+        float4 done[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            store_split4(nxt * NS * LH_AP + a_row[i], xc[i].x * rstd[i], xc[i].y * rstd[i], xc[i].z * rstd[i], xc[i].w * rstd[i]);
+            pin_here(rr[i]);
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * LSP + l_row[i]]);
+            done[i] = make_float4(rr[i].x + pv.x, rr[i].y + pv.y, rr[i].z + pv.z, rr[i].w + pv.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // group 2: k-step 2  +  this step's own global traffic
+        mfma_ks(2);
+#if defined(LH_PROBE_NOSTORE)
+        if (it >= 2 && done[0].x == 1.2345e30f) {
+#else
+        if (it >= 2) {
+#endif
+            char* base = ob + step_pos(it - 2) * step_bytes;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) *reinterpret_cast<float4*>(base + voff[i]) = done[i];
+        }
+#if defined(LH_PROBE_NOLOAD)
+        if (it < 2) {
+            load_base(it - 1, rr);
+            load_x(it + 2, xr);
+        }
+#else
+        load_base(it - 1, rr);                        // consumed next iteration (clamped at it = 0: unused)
+        load_x(it + 2, xr);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        LH_STAMP(1);
+        // group 3: k-step 3 and the projection
+        mfma_ks(3);
         lin_tile(cur, cur);                           // projection of h_{it-1} (at it = 0: of the initial state, unused)
+        __builtin_amdgcn_sched_barrier(0);
+        LH_STAMP(2);
+        __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                lstm_cell_pre(gate[m][0][r], gate[m][1][r], gate[m][2][r], gate[m][3][r], creg[m][r], hreg[m][r]);
+                float hv;
+                lstm_cell_pre(gate[m][0][r], gate[m][1][r], gate[m][2][r], gate[m][3][r], creg[m][r], hv);
                 _Float16 th, tl;
-                split_f16(hreg[m][r], th, tl);
+                split_f16(hv, th, tl);
                 ahi[(nxt * NS + m * 16 + r) * LH_AP + a_cell] = th;
                 alo[(nxt * NS + m * 16 + r) * LH_AP + a_cell] = tl;
             }
+        __builtin_amdgcn_sched_barrier(0);
+        LH_STAMP(3);
         __syncthreads();
     };
     {
@@ -656,279 +704,33 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
         if (it < nstep) step(it, std::integral_constant<int, 0>{});
     }
 
+#if defined(LH_PROBE_TRACE)
+    if (tr_slot >= 0 && dir == 0 && threadIdx.x < 64)
+        for (int i = threadIdx.x; i < 128 * 4; i += 64) lh_trace_buf[tr_slot * 512 + i] = tr[i];
+#endif
     // ---- drain: rows of the last two steps
     if (nstep >= 2) store_rows(nstep - 2, (nstep - 1) & 1, rr);
     load_base(nstep - 1, rr);
     lin_tile(nstep & 1, nstep & 1);                   // projection of h_{nstep-1}
     __syncthreads();
     store_rows(nstep - 1, nstep & 1, rr);
-    if (hN) {                                         // final hidden state: cell layout -> rows, through LDS
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hf[(m * 16 + r) * LSP + l_cell] = hreg[m][r];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int rl = (tid + 256 * i) >> 4;
-            if (s0 + rl < nseq)
-                *reinterpret_cast<float4*>(&hN[(long)(s0 + rl) * H + q * 4]) =
-                    *reinterpret_cast<const float4*>(&hf[l_row[i]]);
-        }
-    }
-    if (cN) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int s = s0 + m * 16 + g4 * 4 + r;
-                if (s < nseq) cN[(long)s * H + unit] = creg[m][r];
-            }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Eight-wave variant of the fused recurrence for the LATENCY-bound regime (the inter pass: 625 dependent steps and, at
-// batch 32, only 194 sixteen-sequence tiles for 256 CUs, i.e. one workgroup per CU and — with four waves — one wave per
-// SIMD that serialises its own LDS / MFMA / transcendental latencies: 1.14 us per step against 0.8 us of issue time).
-// Same tile (16 sequences, all steps), same LDS images, but 512 threads: two waves per SIMD that cover each other's
-// stalls.  Wave v owns hidden units 8v..8v+7 of all four gates; the gate GEMM is TRANSPOSED (weights are the MFMA A
-// operand, activations the B operand) so that the accumulator tile is [16 gate columns] x [16 sequences] with rows
-// ordered (unit, gate): a lane then holds the four gates of ONE unit of ONE sequence in the four registers of a tile
-// and the cell update stays lane-local with two cells per lane.  Waves 0..3 also run the output projection of
-// h_{t-1} (their B fragments of the h half double as its A operand) and finish / fetch the output rows; waves 4..7
-// normalise and split x_{t+1}.  Each SIMD hosts one wave of either kind.
-// ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512, 1) k_lstm_lin8(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
-                                                      const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
-                                                      const float* __restrict__ blin, const float* __restrict__ h0,
-                                                      const float* __restrict__ c0, float* __restrict__ hN,
-                                                      float* __restrict__ cN, float* out, int nseq, int nstep, int sdiv,
-                                                      int so, int si, int ps, int dir, int accumulate) {
-    constexpr int NS = 16;
-    constexpr int LSP = C + 4;
-    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
-    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
-    __shared__ __attribute__((aligned(16))) float ls[2 * NS * LSP];
-    __shared__ __attribute__((aligned(16))) float hf[NS * LSP];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the role branches below are s_cbranch
-    const int s0 = blockIdx.x * NS;
-    const int g4 = lane >> 4, l15 = lane & 15;
-    const bool lin_wave = wave < 4;                  // wave-uniform role
-    const int q = tid & 15, rrow = (tid & 255) >> 4; // row-wise roles: float4 q of row rrow
-    const int unit0 = 8 * wave + g4;                 // this lane's cells: units unit0 and unit0 + 4 of sequence l15
-
-    auto row_of0 = [&](int s) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si; };
-    const long wg_row0 = row_of0(min(s0, nseq - 1));
-    const unsigned voff = (unsigned)((row_of0(min(s0 + rrow, nseq - 1)) - wg_row0) * (C * 4) + q * 16);
-    const char* xb = reinterpret_cast<const char*>(x) + wg_row0 * (C * 4);
-    char* ob = reinterpret_cast<char*>(out) + wg_row0 * (C * 4);
-    // base of the projection rows: pass 0 the residual x, an accumulating pass the partial sums already in `out`
-    // (integer select: a select between two pointers is lowered to a table in scratch memory)
-    const char* bsrc = reinterpret_cast<const char*>(
-        accumulate ? reinterpret_cast<unsigned long long>(ob) : reinterpret_cast<unsigned long long>(xb));
-    const long step_bytes = (long)ps * (C * 4);
-    auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
-
-    // resident weights: A-operand fragments [tile][kstep] of this wave's 32 gate columns (image: weights.py
-    // pack_lstm_f16x3_w8), the projection's B fragments (waves 0..3), biases of the lane's two units
-    f16x8 wh[2][4], wl[2][4];
-    {
-        const _Float16* wp = w_pk + ((long)(dir * 8 + wave) * 8 * 64 + lane) * 16;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                wh[m][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(m * 4 + ks) * 64 * 16);
-                wl[m][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(m * 4 + ks) * 64 * 16 + 8);
-            }
-    }
-    f16x8 lwh[2], lwl[2];
-    float lbias = 0.0f;
-    if (lin_wave) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            lwh[ks] = *reinterpret_cast<const f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16]);
-            lwl[ks] = *reinterpret_cast<const f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16 + 8]);
-        }
-        if (!accumulate) lbias = blin[wave * 16 + l15];
-    } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) lwh[ks] = lwl[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    float bias[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias[m][g] = b_sum[dir * 256 + g * 64 + unit0 + 4 * m];
-
-    const int a_frag = l15 * LH_AP + g4 * 8;         // B operand of the gate GEMM / A operand of the projection
-    const int a_cell = l15 * LH_AP + C + unit0;      // where this lane's h values go (+ 4 m)
-    const int a_row = rrow * LH_AP + q * 4;
-    const int l_row = rrow * LSP + q * 4;
-    const int l_lin = (g4 * 4) * LSP + wave * 16 + l15;
-
-    auto store_split4 = [&](int idx, float a, float b, float c, float d) {
-        f16x4 h4, l4;
-        _Float16 th, tl;
-        split_f16(a, th, tl); h4[0] = th; l4[0] = tl;
-        split_f16(b, th, tl); h4[1] = th; l4[1] = tl;
-        split_f16(c, th, tl); h4[2] = th; l4[2] = tl;
-        split_f16(d, th, tl); h4[3] = th; l4[3] = tl;
-        *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
-        *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
-    };
-    auto norm_store_x = [&](int buf, float4 v) {
-        const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
-        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-        const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
-        const float rstd = __builtin_amdgcn_rsqf(var + LN_EPS);
-        store_split4(buf * NS * LH_AP + a_row, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
-    };
-    auto load_row = [&](const char* base, int it) -> float4 {
-        return *reinterpret_cast<const float4*>(base + step_pos(it) * step_bytes + voff);
-    };
-
-    // ---- prologue
-    float creg[2], hreg[2];
-    // the one global row a thread carries from step to step: waves 4..7 x_{it+1} (fetched a step ahead), waves 0..3 the
-    // base of the projection rows of step it-2
-    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!lin_wave) {
-        norm_store_x(0, load_row(xb, 0));
-        carry = load_row(xb, 1);
-    } else {
-        const int s = min(s0 + rrow, nseq - 1);
-        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
-        store_split4(a_row + C, hv.x, hv.y, hv.z, hv.w);
-    }
-    {
-        const int s = min(s0 + l15, nseq - 1);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            creg[m] = c0 ? c0[(long)s * H + unit0 + 4 * m] : 0.0f;
-            hreg[m] = 0.0f;
-        }
-    }
-    __syncthreads();
-
-    auto step = [&](int it, auto cur_tag) __attribute__((always_inline)) {
-        constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
-        // row-wise roles first: consumers of the global loads issued one step ago, then this step's own global traffic
-        pin_here(carry);
-        if (lin_wave) {
-            const float4 pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * LSP + l_row]);
-            const float4 done = make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
-            __builtin_amdgcn_sched_barrier(0);
-            if (it >= 2) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done;
-            carry = load_row(bsrc, it - 1);
-        } else {
-            norm_store_x(nxt, carry);
-            __builtin_amdgcn_sched_barrier(0);
-            carry = load_row(xb, it + 2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        f32x4 acc[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) acc[m] = f32x4{bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
-        f16x8 bh[4], bl[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bh[ks] = *reinterpret_cast<const f16x8*>(&ahi[cur * NS * LH_AP + a_frag + ks * 32]);
-            bl[ks] = *reinterpret_cast<const f16x8*>(&alo[cur * NS * LH_AP + a_frag + ks * 32]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][ks], bh[ks], acc[m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][ks], bl[ks], acc[m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[m][ks], bh[ks], acc[m], 0, 0, 0);
-        }
-        if (lin_wave) {                               // projection of h_{it-1}: rows = sequences, this wave's 16 output columns
-            f32x4 am = f32x4{lbias, lbias, lbias, lbias};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[2 + ks], lwh[ks], am, 0, 0, 0);
-                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[2 + ks], lwl[ks], am, 0, 0, 0);
-                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[2 + ks], lwh[ks], am, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ls[cur * NS * LSP + r * LSP + l_lin] = am[r];
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            lstm_cell_pre(acc[m][0], acc[m][1], acc[m][2], acc[m][3], creg[m], hreg[m]);
-            _Float16 th, tl;
-            split_f16(hreg[m], th, tl);
-            ahi[nxt * NS * LH_AP + a_cell + 4 * m] = th;
-            alo[nxt * NS * LH_AP + a_cell + 4 * m] = tl;
-        }
-        __syncthreads();
-    };
-    {
-        int it = 0;
-        for (; it + 1 < nstep; it += 2) {
-            step(it, std::integral_constant<int, 0>{});
-            step(it + 1, std::integral_constant<int, 1>{});
-        }
-        if (it < nstep) step(it, std::integral_constant<int, 0>{});
-    }
-
-    // ---- drain: rows of the last two steps (projection of h_{nstep-1} still to do)
-    const int lastb = nstep & 1;
-    if (lin_wave) {
-        if (nstep >= 2) {
-            const float4 pv = *reinterpret_cast<const float4*>(&ls[(lastb ^ 1) * NS * LSP + l_row]);
-            *reinterpret_cast<float4*>(ob + step_pos(nstep - 2) * step_bytes + voff) =
-                make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
-        }
-        carry = load_row(bsrc, nstep - 1);
-        f32x4 am = f32x4{lbias, lbias, lbias, lbias};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[lastb * NS * LH_AP + a_frag + (2 + ks) * 32]);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[lastb * NS * LH_AP + a_frag + (2 + ks) * 32]);
-            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwh[ks], am, 0, 0, 0);
-            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwl[ks], am, 0, 0, 0);
-            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, lwh[ks], am, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ls[lastb * NS * LSP + r * LSP + l_lin] = am[r];
-    }
-    if (hN) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) hf[l15 * LSP + unit0 + 4 * m] = hreg[m];
-    }
-    __syncthreads();
-    if (lin_wave) {
-        const float4 pv = *reinterpret_cast<const float4*>(&ls[lastb * NS * LSP + l_row]);
-        *reinterpret_cast<float4*>(ob + step_pos(nstep - 1) * step_bytes + voff) =
-            make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
-    } else if (hN && s0 + rrow < nseq) {
-        *reinterpret_cast<float4*>(&hN[(long)(s0 + rrow) * H + q * 4]) = *reinterpret_cast<const float4*>(&hf[l_row]);
-    }
-    if (cN && s0 + l15 < nseq) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + 4 * m] = creg[m];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Software-pipelined eight-wave recurrence (k_lstm_lin8p).  Same tile, roles, weight image and LDS rows as k_lstm_lin8,
-// but the NON-recurrent half of the gate GEMM — LN(x_{t+1}) W_ih'^T + b, K = 64 of the 128 — leaves the dependent chain:
-// it is computed during step t, after the recurrent half of step t has been issued, so its 12 MFMAs per wave (plus the
-// 6 of the output projection on waves 0..3) run in the matrix pipe underneath the transcendental-heavy cell update of
-// step t (MFMA and VALU of one SIMD overlap: an MFMA holds the vector issue port for ~8 of its ~19 cycles,
-// profiles/r02a_ubench_issue_model.txt).  The chain of a step is then
-//     barrier -> ds_read h -> 12 MFMA (K = 64, accumulators start from the pre-computed x half) -> cells -> ds_write h
-// instead of 24 (+6) MFMAs ahead of the cells.  The x half of the LDS rows runs one step further ahead than the h
-// half: during step t buffer (t & 1) receives x_{t+2} (its x_t was consumed in step t-1) while x_{t+1} is read from
-// buffer (t+1) & 1; the h halves alternate as before.
+// Eight-wave, software-pipelined fused recurrence for the inter pass (k_lstm_lin8p): 625 dependent steps and, at batch 32,
+// only 194 sixteen-sequence tiles for 256 CUs, i.e. one workgroup per CU.  Same tile (16 sequences, all steps) and LDS
+// images as k_ln_lstm_lin, but 512 threads, two waves per SIMD.  Wave v owns hidden units 8v..8v+7 of all four gates;
+// the gate GEMM is TRANSPOSED (weights are the MFMA A operand, activations the B operand) so that the accumulator tile
+// is [16 gate columns] x [16 sequences] with rows ordered (unit, gate): a lane then holds the four gates of ONE unit of
+// ONE sequence in the four registers of a tile and the cell update stays lane-local with two cells per lane.  Waves
+// 0..3 ("LIN") also run the output projection of h_{t-1} (their B fragments of the h half double as its A operand) and
+// finish / fetch the output rows; waves 4..7 normalise and split x.  Each SIMD hosts one wave of either kind.
+// The NON-recurrent half of the gate GEMM — LN(x_{t+1}) W_ih'^T + b, K = 64 of the 128 — is off the dependent chain:
+// it is computed during step t, after the recurrent half of step t, so the chain of a step is
+//     barrier -> ds_read h -> 12 MFMA (K = 64, accumulators start from the pre-computed x half) -> cells -> ds_write h.
+// The x half of the LDS rows therefore runs one step further ahead than the h half: during step t buffer (t & 1)
+// receives x_{t+2} (its x_t was consumed in step t-1) while x_{t+1} is read from buffer (t+1) & 1; the h halves
+// alternate as usual.  Measured 1.70 ms per bench step (3 launches) against 1.82 for the un-pipelined form.
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
                                                        const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
@@ -1064,21 +866,7 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
     auto step = [&](int it, auto cur_tag, auto lin_tag) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
         constexpr bool LIN = decltype(lin_tag)::value;
-        pin_here(carry);
-        if (LIN) {
-            const float4 pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * LSP + l_row]);
-            const float4 done = make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
-            __builtin_amdgcn_sched_barrier(0);
-            if (it >= 2) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done;
-            carry = load_row(bsrc, it - 1);
-        } else {
-            norm_store_x(cur, carry);                 // x_{it+2}
-            __builtin_amdgcn_sched_barrier(0);
-            carry = load_row(xb, it + 3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // recurrent half: acc = (x half of this step, computed a step ago) + h_{it-1} W_hh^T
+        // recurrent half first: acc = (x half of this step, computed a step ago) + h_{it-1} W_hh^T ...
         f16x8 bh[2], bl[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1095,10 +883,24 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[m][2 + ks], bh[ks], acc[m], 0, 0, 0);
         }
+        // ... with the wave's row-wise role in the shadow of those MFMAs (in-order issue: in front of them it would delay
+        // the chain by its full length): consumers of the global loads issued one step ago, then this step's own traffic
+        pin_here(carry);
+        if (LIN) {
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * LSP + l_row]);
+            const float4 done = make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+            if (it >= 2) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done;
+            carry = load_row(bsrc, it - 1);
+        } else {
+            norm_store_x(cur, carry);                 // x_{it+2}
+            carry = load_row(xb, it + 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // Off the chain: x half of step it+1 (buffer nxt holds x_{it+1}) and, on waves 0..3, the projection of h_{it-1}.
         // The two waves of a SIMD take opposite orders: the LIN wave issues its 18 off-chain MFMAs first and updates its
-        // cells afterwards, the other wave updates its cells first — one wave's transcendentals run under the other's
-        // matrix work (in-order issue inside a wave would otherwise queue the cells behind both waves' MFMAs).
+        // cells afterwards, the other wave updates its cells first.  (A SIMD issues matrix and vector instructions from
+        // one port and they do not overlap — profiles/r02d_lstm_issue_probes.txt; cutting the cell update into
+        // micro-stages behind each off-chain MFMA measured 1.84 ms per step against 1.70 for this form.)
         auto cells = [&]() {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -1142,7 +944,7 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
     if (lin_wave) run(std::true_type{});
     else run(std::false_type{});
 
-    // ---- drain (as k_lstm_lin8)
+    // ---- drain: rows of the last two steps (projection of h_{nstep-1} still to do)
     const int lastb = nstep & 1;
     if (lin_wave) {
         if (nstep >= 2) {
@@ -1228,12 +1030,17 @@ static int cu_count() {
     }
     return n;
 }
-static int g_tune[4] = {0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [3] 0 = no issue-priority de-phasing
+static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [3] 0 = no issue-priority de-phasing
 }
 namespace lh { int attn_set_mq(int v); }      // lh_attn.hip
+#if defined(LH_PROBE_TRACE)
+extern "C" int lh_probe_trace_read(unsigned long long* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::lh_trace_buf), sizeof(lh::lh_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" int lh_set_tuning(int key, int value) {
     if (key == 4) return lh::attn_set_mq(value);
-    if (key < 0 || key >= 4) return LH_ERR_ARG;
+    if (key < 0 || key >= 8) return LH_ERR_ARG;
     lh::g_tune[key] = value;
     if (key == 3) lh::g_dephase = value;
     return LH_OK;
@@ -1323,14 +1130,10 @@ extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_s
     using namespace lh;
     if (!x || !w_pk || !b_sum || !wlin_pk || !blin || !h0 || !c0 || !hN || !cN || !out || B <= 0 || T <= 0) return LH_ERR_ARG;
     if (h0 == hN || c0 == cN || x == out) return LH_ERR_ARG;
-    // sequence s = b*97 + f; step = frame t; row(s, t) = (b*T + t)*97 + f.  Eight-wave tiles (k_lstm_lin8): the pass is a
+    // sequence s = b*97 + f; step = frame t; row(s, t) = (b*T + t)*97 + f.  Eight-wave tiles (k_lstm_lin8p): the pass is a
     // 625-step dependent chain, two waves per SIMD cover each other's latencies
     const int nseq = B * NF;
-    if (g_tune[2] == 1)      // A/B: the un-pipelined eight-wave kernel
-        hipLaunchKernelGGL(k_lstm_lin8, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,
-                           b_sum, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF, 0, 0);
-    else
-        hipLaunchKernelGGL(k_lstm_lin8p, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,
+    hipLaunchKernelGGL(k_lstm_lin8p, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,
                            b_sum, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF, 0, 0);
     return check_launch();
 }

@@ -111,7 +111,7 @@ def pack_lstm_f16x3(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
 
 
 def pack_lstm_f16x3_w8(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
-    """Image of the eight-wave fused kernel (lh_lstm.hip k_lstm_lin8), where the weights are the MFMA **A** operand of a
+    """Image of the eight-wave fused kernel (lh_lstm.hip k_lstm_lin8p), where the weights are the MFMA **A** operand of a
     transposed gate GEMM: [8 waves, 2 tiles, 4 ksteps, 64 lanes, 2 (hi|lo), 8] fp16, lo unscaled, rows pre-scaled by
     `gate_prescale`.  Lane l of (wave v, tile m, k-step ks) holds row  gate*64 + unit  of [W_ih | W_hh] with
     gate = (l & 15) & 3, unit = 8v + 4m + ((l & 15) >> 2), at k = ks*32 + (l >> 4)*8 + j: the accumulator tile is then

@@ -1,0 +1,43 @@
+"""Timing probe (not product code): per-step s_memtime stamps of two workgroups of the fused intra kernel.
+
+Run on the GPU box with the -DLH_PROBE_TRACE build:
+    LOOKONCE_HIP_LIB=$PWD/lookoncetohear_amd/_lookonce_hip_probe_TRACE.so python scripts/probe_trace.py
+Stamps per step: 0 = top of step (behind the barrier), 1 = row-wise work + global traffic issued, 2 = all MFMAs issued,
+3 = cell update issued (in front of the barrier).  s_memtime ticks at a constant 100 MHz.
+"""
+import ctypes
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from lookoncetohear_amd import _cabi, config, synth  # noqa: E402
+from lookoncetohear_amd.net import Net  # noqa: E402
+
+tune = [kv.split("=") for kv in sys.argv[1:]]
+net = Net(**config.TSH_PARAMS).eval()
+net.load_state_dict(config.separator_weights(0), strict=True)
+net = net.to("cuda:0")
+lib = _cabi.load()
+for k, v in tune:
+    lib.raw("lh_set_tuning")(int(k), int(v))
+d = synth.batch(list(range(32)), 80000)
+x, e = d["mixture"].to("cuda:0"), d["embedding_gt"].to("cuda:0")
+with torch.no_grad():
+    for _ in range(3):
+        net(x, e)
+torch.cuda.synchronize()
+buf = np.zeros(2 * 128 * 4, dtype=np.uint64)
+rc = lib.raw("lh_probe_trace_read")(buf.ctypes.data_as(ctypes.c_void_p))
+assert rc == 0
+t = buf.reshape(2, 128, 4)[:, :97].astype(np.int64)
+for w, name in enumerate(["workgroup 7 (first round)", "workgroup n-9 (last round)"]):
+    tt = t[w]
+    step = np.diff(tt[:, 0])
+    seg = np.stack([tt[:, 1] - tt[:, 0], tt[:, 2] - tt[:, 1], tt[:, 3] - tt[:, 2]], 1)
+    bar = tt[1:, 0] - tt[:-1, 3]
+    print(name, "ticks per step (median / p10 / p90):", np.median(step), np.percentile(step, 10), np.percentile(step, 90))
+    print("   segments median: rows %.1f  mfma %.1f  cells %.1f  barrier %.1f" %
+          (np.median(seg[:, 0]), np.median(seg[:, 1]), np.median(seg[:, 2]), np.median(bar)))
+    print("   first 12 steps:", step[:12].tolist())
