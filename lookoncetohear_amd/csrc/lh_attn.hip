@@ -4,9 +4,9 @@
 // tfgridnet_causal.py:429-454: 67 % of its CPU time).  Here a workgroup owns TQ = 16*MQ consecutive query frames of
 // one (batch, head): the TQ+49 history-extended K/V rows they can see are read ONCE from the ring-extended buffers.
 //
-// Q, K and V arrive as split-precision fp16 pairs (v = hi + 2^-11 lo, written by k_qkv_proj_ln in exactly the order
-// the v_mfma_f32_16x16x32_f16 operands want, lh_common.h), so both contractions run as three fp16 MFMAs per tile
-// (hi*hi + 2^-11 (hi*lo + lo*hi), ~22 mantissa bits) with no conversion work in this kernel:
+// Q, K and V arrive as split-precision fp16 pairs (v = hi + lo, lo un-rescaled; written by k_qkv_proj_ln in exactly the
+// order the v_mfma_f32_16x16x32_f16 operands want, lh_common.h), so both contractions run as three fp16 MFMAs per tile
+// (hi*hi + hi*lo + lo*hi into one accumulator, ~22 mantissa bits) with no conversion work in this kernel:
 //   * scores  S = Q K^T: banded tile products (query tile mq x key tiles mq..mq+4), the 19 feature k-steps split
 //     over the 4 waves, partial sums reduced through LDS; A and B fragments are 32-byte row segments straight from
 //     global memory (two-deep register ring);
@@ -56,18 +56,14 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
     const _Float16* qb = q + (long)bh * T * LDQKH;
     const _Float16* kb = kx + ((long)bh * TKP + t0) * LDQKH;
     const _Float16* vb = vx + ((long)bh * TKP + t0) * LDVH;
-    constexpr float INV = 1.0f / SPLIT_F;
 
     // ---- scores: S[i][n] = <Q[t0+i], Kx[t0+n]>, feature k-steps s = wave, wave+4, ... of 19
     {
-        f32x4 am[MQ][ND], ac[MQ][ND];
+        f32x4 am[MQ][ND];
 #pragma unroll
         for (int mq = 0; mq < MQ; ++mq)
 #pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                am[mq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-                ac[mq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int d = 0; d < ND; ++d) am[mq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
         int qoff[MQ], koff[NKT];
 #pragma unroll
         for (int mq = 0; mq < MQ; ++mq) qoff[mq] = min(t0 + mq * 16 + l15, T - 1) * LDQKH + g4 * 16;
@@ -97,8 +93,8 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
                 for (int d = 0; d < ND; ++d) {
                     const Frag& kf = sk[mq + d];
                     am[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].h, kf.h, am[mq][d], 0, 0, 0);
-                    ac[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].h, kf.l, ac[mq][d], 0, 0, 0);
-                    ac[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].l, kf.h, ac[mq][d], 0, 0, 0);
+                    am[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].h, kf.l, am[mq][d], 0, 0, 0);
+                    am[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].l, kf.h, am[mq][d], 0, 0, 0);
                 }
         };
         fetch(0, fq[0], fk[0]);
@@ -113,7 +109,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
             for (int d = 0; d < ND; ++d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    sp[wave][mq * 16 + g4 * 4 + r][(mq + d) * 16 + l15] = am[mq][d][r] + ac[mq][d][r] * INV;
+                    sp[wave][mq * 16 + g4 * 4 + r][(mq + d) * 16 + l15] = am[mq][d][r];
     }
     __syncthreads();
 
@@ -150,7 +146,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
                 const float p = sv[u] * inv;           // exactly 0 outside the band
                 const _Float16 h = (_Float16)p;
                 ph[i][sub + 16 * u] = h;
-                pl[i][sub + 16 * u] = (_Float16)((p - (float)h) * SPLIT_F);
+                pl[i][sub + 16 * u] = (_Float16)(p - (float)h);
             }
         }
     }
@@ -185,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
         };
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s) fill(s % RING, s % AT_PKS, qcol(wave + 4 * (part + nsplit * (s / AT_PKS))));
-        f32x4 am[MQ][4], ac[MQ][4];
+        f32x4 am[MQ][4];
         // fully unrolled (7 column groups for wave 0, 6 for the others): exact vmcnt waits instead of a drain of the
         // ring at every loop back-edge
         constexpr int NSTEP = ((AT_CG + 3) / 4) * AT_PKS;
@@ -197,10 +193,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
 #pragma unroll
                 for (int mq = 0; mq < MQ; ++mq)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        am[mq][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        ac[mq][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
+                    for (int c = 0; c < 4; ++c) am[mq][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             {
                 const int sn = s + RING - 1, cgn = wave + 4 * (part + nsplit * (sn / AT_PKS));
@@ -222,8 +215,8 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     am[mq][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bh8[c], am[mq][c], 0, 0, 0);
-                    ac[mq][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bl8[c], ac[mq][c], 0, 0, 0);
-                    ac[mq][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, bh8[c], ac[mq][c], 0, 0, 0);
+                    am[mq][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bl8[c], am[mq][c], 0, 0, 0);
+                    am[mq][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, bh8[c], am[mq][c], 0, 0, 0);
                 }
             }
             const int col = cg * 64 + l15 * 4;
@@ -235,8 +228,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
                         const int t = t0 + mq * 16 + g4 * 4 + r;
                         if (t < T)      // head-major slab [b][t][hd][f][v]: one head's frame is 6208 contiguous bytes
                             *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * NH + hd) * DV + col]) =
-                                make_float4(am[mq][0][r] + ac[mq][0][r] * INV, am[mq][1][r] + ac[mq][1][r] * INV,
-                                            am[mq][2][r] + ac[mq][2][r] * INV, am[mq][3][r] + ac[mq][3][r] * INV);
+                                make_float4(am[mq][0][r], am[mq][1][r], am[mq][2][r], am[mq][3][r]);
                     }
             }
         }
@@ -247,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
 // Streaming state <-> ring rows: the reference carries K_buf [4B][49][582] / V_buf [4B][49][1552] as fp32
 // (tfgridnet_causal.py:553-562); the history rows of kx / vx hold the same numbers as split fp16 pairs.
 //   pack:   rows 0..48 of kx / vx   <- K_buf / V_buf
-//   unpack: K_buf / V_buf           <- rows T..T+48 of kx / vx  (hi + 2^-11 lo: the value the attention kernel used)
+//   unpack: K_buf / V_buf           <- rows T..T+48 of kx / vx  (hi + lo: the value the attention kernel used)
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ring_pack(const float* __restrict__ kbuf, const float* __restrict__ vbuf,
                                                    _Float16* __restrict__ kx, _Float16* __restrict__ vx, long tkp, int BH) {
@@ -264,7 +256,7 @@ __global__ void __launch_bounds__(256) k_ring_pack(const float* __restrict__ kbu
                 const float v = f < DQK ? kbuf[row * DQK + f] : 0.f;
                 const _Float16 h = (_Float16)v;
                 h8[e] = h;
-                l8[e] = (_Float16)((v - (float)h) * SPLIT_F);
+                l8[e] = (_Float16)(v - (float)h);
             }
             _Float16* d = kx + (bh * tkp + r) * LDQKH + blk * 16;
             *reinterpret_cast<f16x8*>(d) = h8;
@@ -281,7 +273,7 @@ __global__ void __launch_bounds__(256) k_ring_pack(const float* __restrict__ kbu
             for (int e = 0; e < 4; ++e) {
                 const _Float16 h = (_Float16)v[e];
                 o[e] = h;
-                o[4 + e] = (_Float16)((v[e] - (float)h) * SPLIT_F);
+                o[4 + e] = (_Float16)(v[e] - (float)h);
             }
             *reinterpret_cast<f16x8*>(vx + (bh * tkp + r) * LDVH + qd * 8) = o;
         }
@@ -292,7 +284,6 @@ __global__ void __launch_bounds__(256) k_ring_unpack(const _Float16* __restrict_
                                                      float* __restrict__ kbuf, float* __restrict__ vbuf, long tkp, int T,
                                                      int BH) {
     const long nk = (long)BH * HIST * QKB, nv = (long)BH * HIST * (DV / 4);
-    constexpr float INV = 1.0f / SPLIT_F;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nk + nv; i += (long)gridDim.x * 256) {
         if (i < nk) {
             const long row = i / QKB;
@@ -303,7 +294,7 @@ __global__ void __launch_bounds__(256) k_ring_unpack(const _Float16* __restrict_
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int f = blk * 8 + e;
-                if (f < DQK) kbuf[row * DQK + f] = (float)h8[e] + (float)l8[e] * INV;
+                if (f < DQK) kbuf[row * DQK + f] = (float)h8[e] + (float)l8[e];
             }
         } else {
             const long k = i - nk;
@@ -312,8 +303,8 @@ __global__ void __launch_bounds__(256) k_ring_unpack(const _Float16* __restrict_
             const long bh = row / HIST, r = row % HIST;
             const f16x8 o = *reinterpret_cast<const f16x8*>(vx + (bh * tkp + T + r) * LDVH + qd * 8);
             *reinterpret_cast<float4*>(&vbuf[row * DV + qd * 4]) =
-                make_float4((float)o[0] + (float)o[4] * INV, (float)o[1] + (float)o[5] * INV,
-                            (float)o[2] + (float)o[6] * INV, (float)o[3] + (float)o[7] * INV);
+                make_float4((float)o[0] + (float)o[4], (float)o[1] + (float)o[5], (float)o[2] + (float)o[6],
+                            (float)o[3] + (float)o[7]);
         }
     }
 }
@@ -336,7 +327,8 @@ extern "C" int lh_local_attn(const void* q, const void* kx, const void* vx, floa
     // a single query tile when the clip is that short (streaming: T = 1) — the second tile would be all padding
     // two query tiles per workgroup share every K / V row they load (25 instead of 44 KB of L2 traffic per query;
     // measured 0.36 against 0.43 ms at B = 32); a single tile when the clip is that short (streaming: T = 1).
-    // The two-tile kernel runs a two-deep V ring: with three slots it needs more than 256 registers.
+    // The two-tile kernel runs a two-deep V ring: a three-deep one (228 registers since the single-accumulator split)
+    // measured 3 % slower.
     const int mq = T <= 16 ? 1 : g_attn_mq;
     const int ntt = (T + 16 * mq - 1) / (16 * mq);
     // latency-bound launches (a handful of workgroups): split the V columns of a tile over 7 workgroups

@@ -8,7 +8,7 @@
 // the 16 spectra Sx[t0..t0+15] (Sx[0] = carried istft_buf) are assembled in LDS as a second A image, and the
 // synthesis filterbank ([194 x 192], resident in VGPRs as B fragments for the whole kernel) turns them into 16 frames
 // per source that are overlap-added into 15 x 128 output samples.
-// Both contractions run on split-precision fp16 MFMA (v = hi + 2^-11 lo, three v_mfma_f32_16x16x32_f16 per product,
+// Both contractions run on split-precision fp16 MFMA (v = hi + lo, three v_mfma_f32_16x16x32_f16 per product,
 // lh_split.h): the exact-fp32 MFMA version of this kernel spent 5x the matrix cycles and, at one wave per SIMD
 // (386 registers), could not hide them: 0.46 ms per call at B = 32 against an HBM floor of 0.08 ms.
 #include "lh_split.h"
@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                                                         float* __restrict__ dbuf_out, const float* __restrict__ ibuf_in,
                                                         float* __restrict__ ibuf_out, const _Float16* __restrict__ wd_pk,
                                                         const float* __restrict__ bd, const _Float16* __restrict__ wfb_pk,
-                                                        float* __restrict__ wave_out, int B, int T) {
+                                                        float* __restrict__ wave_out, int B, int T, int runs_per_b) {
     // Two input frames per loop iteration (half the barriers; at one frame the loop was ~80 % stall): two A images, and
     // a partial-product ring of 4 frames (2 being written while the gather still reads the 2 before them).
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * FR_A];                 // A images of two input frames
@@ -62,12 +62,34 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     for (int i = tid; i < NSRC * BE_SA; i += BE_NT) { sxh[i] = (_Float16)0.f; sxl[i] = (_Float16)0.f; }
     for (int i = tid; i < 4 * 2 * BE_PP; i += BE_NT) pring[i / (2 * BE_PP)][((i / BE_PP) & 1) * (NF + 1)][i % BE_PP] = 0.f;
 
+    // A workgroup walks a RUN of consecutive tiles of one utterance: only the run's first tile pays the 3-frame halo
+    // (re-multiplying frames t0-3 .. t0-1); later tiles find the partial products of frames t0-2, t0-1 still in the ring
+    // and take Sx[0] (= the spectrum of frame t0-1) from the previous tile's row 15.  At 42 tiles per 5 s clip the halo
+    // was 20 % extra frames (PMC: 1.42x the algorithmic bytes); 8 runs per utterance at B = 32 make it 4 %.
     const int tiles_per_b = (T + BE_TT - 1) / BE_TT;
+    const int n_runs = B * runs_per_b;
     const long L = (long)HOP * T;
-    for (int tile = blockIdx.x; tile < B * tiles_per_b; tile += gridDim.x) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile % tiles_per_b) * BE_TT;
+    // flat loop over the tiles of this workgroup's runs: runs blockIdx.x, blockIdx.x + gridDim.x, ...; inside a run the
+    // tiles follow each other
+    int run = blockIdx.x, tk = 0, k1 = 0;             // tk == k1: fetch the next run
+    for (;;) {
+        bool first = false;
+        if (tk == k1) {
+            if (run >= n_runs) break;
+            const int rb0 = run % runs_per_b;
+            tk = (int)((long)tiles_per_b * rb0 / runs_per_b);
+            k1 = (int)((long)tiles_per_b * (rb0 + 1) / runs_per_b);
+            first = true;
+        }
+        const int b = run / runs_per_b;
+        {
+        const int t0 = tk * BE_TT;
         const int nt_out = min(BE_TT, T - t0);
+        const bool cont = !first;                     // ring and Sx[15] of the previous tile are this tile's history
+        // `tk >> 30` is always 0 but ties the thread index to the loop variable: without it LICM hoists every per-thread
+        // address of the frame loop out of the persistent loop and the kernel spills ~35 registers (measured 0.28 ms per
+        // call with the hoisted addresses and spills, 0.26 ms with the indices recomputed per tile)
+        const int tv = tid + (tk >> 30);
         __syncthreads();
 
         // one spectrum value -> row jd of source s's A image
@@ -75,18 +97,28 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             const _Float16 h = (_Float16)v;
             const int idx = s * BE_SA + a_index<BE_NJ>(jd, k);
             sxh[idx] = h;
-            sxl[idx] = (_Float16)((v - (float)h) * PW_SPLIT);
+            sxl[idx] = (_Float16)(v - (float)h);
         };
-        // Sx frame 0 of the very first tile is the carried spectrum of the previous call
-        if (t0 == 0)
+        // Sx frame 0: the carried spectrum of the previous call (first tile of the clip), the previous tile's last
+        // frame (inside a run), or recomputed from the halo frames (first tile of a later run)
+        if (t0 == 0) {
             for (int i = tid; i < NSRC * NK; i += BE_NT) put_sx(0, i / NK, i % NK, ibuf_in[(long)b * NSRC * NK + i]);
+        } else if (cont) {
+            for (int i = tid; i < NSRC * NK; i += BE_NT) {
+                const int s = i / NK, k = i % NK;
+                const int src = s * BE_SA + a_index<BE_NJ>(BE_TT, k), dst = s * BE_SA + a_index<BE_NJ>(0, k);
+                sxh[dst] = sxh[src];
+                sxl[dst] = sxl[src];
+            }
+            __syncthreads();                          // row 15 is rewritten by this tile's last frame
+        }
 
         // input frames t0-3 .. t0+nt_out-1 ; after frame fr has been multiplied, output frame td = fr is complete
         float4 stg[BE_RING][BE_NLD];
         auto load_frame = [&](int fr, float4 (&dst)[BE_NLD]) {
 #pragma unroll
             for (int i = 0; i < BE_NLD; ++i) {
-                const int e = min(tid + BE_NT * i, NF * 16 - 1), f = e >> 4, c4 = e & 15;
+                const int e = min(tv + BE_NT * i, NF * 16 - 1), f = e >> 4, c4 = e & 15;
                 if (fr >= 0) {
                     dst[i] = *reinterpret_cast<const float4*>(&y[(((long)b * T + fr) * NF + f) * C + c4 * 4]);
                 } else {                              // carried halo frames, layout [B][64][2][97]
@@ -95,7 +127,14 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                 }
             }
         };
-        const int fr_first = max(t0 - 3, -2);         // frames below -2 do not exist (their taps see nothing)
+        auto load_frame_y = [&](int fr, float4 (&dst)[BE_NLD]) {          // fr >= 0: a frame of y
+#pragma unroll
+            for (int i = 0; i < BE_NLD; ++i) {
+                const int e = min(tv + BE_NT * i, NF * 16 - 1), f = e >> 4, c4 = e & 15;
+                dst[i] = *reinterpret_cast<const float4*>(&y[(((long)b * T + fr) * NF + f) * C + c4 * 4]);
+            }
+        };
+        const int fr_first = cont ? t0 : max(t0 - 3, -2);   // frames below -2 do not exist (their taps see nothing)
         const int fr_end = t0 + nt_out;
         // BE_RING frames in flight per workgroup: with a single one the loop ran at one HBM round trip per frame
 #pragma unroll
@@ -110,15 +149,16 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             // stage the frames into the two A images, refill their ring slots
 #pragma unroll
             for (int i = 0; i < BE_NLD; ++i) {
-                const int e = tid + BE_NT * i;
+                const int e = tv + BE_NT * i;
                 if (e < NF * 16) {
                     store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[u][i]);
                     if (two) store_split4<FR_RP>(ahi + FR_A, alo + FR_A, e >> 4, (e & 15) * 4, stg[u + 1][i]);
                 }
             }
             __syncthreads();
-            if (fr + BE_RING < fr_end) load_frame(fr + BE_RING, stg[u]);
-            if (fr + 1 + BE_RING < fr_end) load_frame(fr + 1 + BE_RING, stg[u + 1]);
+            // (frames fr + BE_RING >= fr_first + 4 >= 2: never the carried halo frames)
+            if (fr + BE_RING < fr_end) load_frame_y(fr + BE_RING, stg[u]);
+            if (fr + 1 + BE_RING < fr_end) load_frame_y(fr + 1 + BE_RING, stg[u + 1]);
 
             // P[fr + q] = Y[fr + q] (97 x 64) * Wd (64 x 48): 2 x 21 (row tile, column tile) products over the 8 waves
             for (int p = wave; p < (two ? 42 : 21); p += 8) {
@@ -141,7 +181,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             __syncthreads();
 
             // output frames td = fr, fr + 1: D[o][f] = b[o] + sum_{kt,kf} P[td-kt][f+1-kf][(kt*3+kf)*4 + o]
-            for (int i = tid; i < (two ? 2 : 1) * 4 * NF; i += BE_NT) {
+            for (int i = tv; i < (two ? 2 : 1) * 4 * NF; i += BE_NT) {
                 const int q = i >= 4 * NF, ii = i - 4 * NF * q;
                 const int td = fr + q;
                 if (td < t0 - 1 || td < 0) continue;
@@ -201,7 +241,16 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
         __syncthreads();
         // frs lived in the hi A images: their pad rows (97..111 feed dropped outputs) must hold finite numbers again
         for (int i = tid; i < 2 * FR_A; i += BE_NT) ahi[i] = (_Float16)0.f;
+        }
+        if (++tk == k1) run += gridDim.x;
     }
+}
+
+static int g_runs_per_b = 0;            // lh_set_tuning key 6: runs per utterance (0 = automatic); tests force 1 on tiny batches
+int backend_set_runs(int v) {
+    if (v < 0) return LH_ERR_ARG;
+    g_runs_per_b = v;
+    return LH_OK;
 }
 
 }  // namespace lh
@@ -215,9 +264,13 @@ extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float
         !wave_out || B <= 0 || T <= 0)
         return LH_ERR_ARG;
     if (deconv_buf_in == deconv_buf_out || istft_buf_in == istft_buf_out) return LH_ERR_ARG;
-    const int tiles = B * ((T + BE_TT - 1) / BE_TT);
-    hipLaunchKernelGGL(k_deconv_istft, dim3(tiles < 256 ? tiles : 256), dim3(BE_NT), 0, (hipStream_t)stream, y,
+    // runs of consecutive tiles: as many per utterance as keep every CU busy (one workgroup per CU), at most one per tile
+    const int tiles_per_b = (T + BE_TT - 1) / BE_TT;
+    int runs_per_b = g_runs_per_b ? g_runs_per_b : 256 / B;
+    runs_per_b = runs_per_b < 1 ? 1 : (runs_per_b > tiles_per_b ? tiles_per_b : runs_per_b);
+    const int n_runs = B * runs_per_b;
+    hipLaunchKernelGGL(k_deconv_istft, dim3(n_runs < 256 ? n_runs : 256), dim3(BE_NT), 0, (hipStream_t)stream, y,
                        deconv_buf_in, deconv_buf_out, istft_buf_in, istft_buf_out, (const _Float16*)wdec_pk, bdec,
-                       (const _Float16*)wfb_dec, wave_out, B, T);
+                       (const _Float16*)wfb_dec, wave_out, B, T, runs_per_b);
     return check_launch();
 }

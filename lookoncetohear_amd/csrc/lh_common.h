@@ -19,7 +19,7 @@ constexpr int E = 6;             // ceil(512/97)
 constexpr int VD = 16;           // C / NH
 constexpr int DQK = NF * E;      // 582
 constexpr int DV = NF * VD;      // 1552
-// Q / K / V live in HBM as split-precision fp16 pairs (v = hi + 2^-11 lo, 4 bytes per element like fp32) in the
+// Q / K / V live in HBM as split-precision fp16 pairs (v = hi + lo, lo un-rescaled; 4 bytes per element like fp32) in the
 // order the attention kernel's v_mfma_f32_16x16x32_f16 operands want:
 //   q, kx rows: 76 blocks of 8 features, each [hi 8 | lo 8] halves (features 582..607 are zero)
 //   vx rows:    388 quads of 4 columns, each [hi 4 | lo 4] halves
@@ -28,7 +28,6 @@ constexpr int DQKP = QKB * 8;    // 608
 constexpr int LDQKH = QKB * 16;  // 1216 halves per q / kx row (2432 bytes)
 constexpr int LDVH = DV * 2;     // 3104 halves per vx row (6208 bytes)
 constexpr int KV_PAD = LH_KV_PAD_ROWS;   // zero rows behind the T+49 rows of kx / vx (tile over-read, never written)
-constexpr float SPLIT_F = 2048.0f;
 constexpr int WIN = 50;          // local_atten_len
 constexpr int HIST = WIN - 1;    // 49 history rows
 constexpr int NQKV = NH * E * 2 + NH * VD;   // 112 projection outputs (Q 24 | K 24 | V 64)

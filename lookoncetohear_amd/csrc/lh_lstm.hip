@@ -1033,6 +1033,7 @@ static int cu_count() {
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [3] 0 = no issue-priority de-phasing
 }
 namespace lh { int attn_set_mq(int v); }      // lh_attn.hip
+namespace lh { int backend_set_runs(int v); } // lh_backend.hip
 #if defined(LH_PROBE_TRACE)
 extern "C" int lh_probe_trace_read(unsigned long long* host_dst) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::lh_trace_buf), sizeof(lh::lh_trace_buf)) == hipSuccess ? 0 : 1;
@@ -1040,6 +1041,7 @@ extern "C" int lh_probe_trace_read(unsigned long long* host_dst) {
 #endif
 extern "C" int lh_set_tuning(int key, int value) {
     if (key == 4) return lh::attn_set_mq(value);
+    if (key == 6) return lh::backend_set_runs(value);
     if (key < 0 || key >= 8) return LH_ERR_ARG;
     lh::g_tune[key] = value;
     if (key == 3) lh::g_dephase = value;

@@ -8,9 +8,9 @@
 //   * global loads of a tile are all issued before the first dependent LDS write (register staging; hipcc does
 //     not unroll a load->ds_write loop by itself and otherwise serialises one HBM round trip per float4), and the
 //     next frame is prefetched into registers while the current one is processed;
-//   * the contraction runs on split-precision fp16 MFMA ("f16x3": v = hi + 2^-11 lo, products hi*hi + 2^-11
-//     (hi*lo + lo*hi) on v_mfma_f32_16x16x32_f16, ~22 mantissa bits, see lh_lstm.hip) so the matrix pipe costs
-//     ~1/5 of fp32 MFMA and stays hidden behind the memory stream;
+//   * the contraction runs on split-precision fp16 MFMA ("f16x3": v = hi + lo, products hi*hi + hi*lo + lo*hi on
+//     v_mfma_f32_16x16x32_f16 into one accumulator, ~22 mantissa bits, lh_split.h) so the matrix pipe costs
+//     ~1/5 of fp32 MFMA;
 //   * each WAVE owns output-column tiles (not row tiles): its weight fragments are 16-32 registers instead of
 //     112-128, which keeps 2-3 workgroups resident per CU for latency hiding;
 //   * LayerNorm / PReLU / residual epilogues run out of LDS with compile-time index algebra.
@@ -160,7 +160,7 @@ struct HeadLN {
                 const float y = x[k][e] * rstd * wv[e] + bv[e];
                 const _Float16 h = (_Float16)y;
                 h8[e] = h;
-                l8[e] = (_Float16)((y - (float)h) * PW_SPLIT);
+                l8[e] = (_Float16)(y - (float)h);
             }
             f16x8 o0 = h8, o1 = l8;
             if (VLAYOUT) {

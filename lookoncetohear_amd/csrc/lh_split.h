@@ -1,5 +1,8 @@
-// Split-precision ("f16x3") building blocks shared by the pointwise, front-end and back-end kernels:
+// Split-precision ("f16x3") building blocks shared by the pointwise, streaming and back-end kernels:
 // A-operand LDS images, resident B fragments and the three-MFMA tile product (see lh_pointwise.hip for the rationale).
+// Split form everywhere in the separator: v = hi + lo with hi = fp16(v), lo = fp16(v - hi), lo NOT rescaled (the matrix
+// core takes fp16 subnormals at full value, profiles/r02a_ubench_issue_model.txt): lo keeps 11 bits while |v| >= 2^-3 and
+// an absolute 2^-25 below that, the three partial products go into ONE fp32 accumulator, and a split costs no multiply.
 #pragma once
 #include "lh_common.h"
 
@@ -7,7 +10,6 @@ namespace lh {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-constexpr float PW_SPLIT = 2048.0f;
 
 // A-operand LDS image for v_mfma_f32_16x16x32_f16: [block = kstep*4 + 16-lane group][row slot][8 halves].
 // Reads: a lane's 16 bytes of consecutive rows are consecutive 16-byte slots.  Writes come row-major from the
@@ -30,7 +32,7 @@ __device__ __forceinline__ void store_split4(_Float16* ahi, _Float16* alo, int r
     for (int i = 0; i < 4; ++i) {
         const _Float16 h = (_Float16)x[i];
         h4[i] = h;
-        l4[i] = (_Float16)((x[i] - (float)h) * PW_SPLIT);
+        l4[i] = (_Float16)(x[i] - (float)h);
     }
     const int idx = a_index<RP>(row, k0);
     *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
@@ -41,6 +43,8 @@ __device__ __forceinline__ void store_split4(_Float16* ahi, _Float16* alo, int r
 template <int RP, int KS>
 __device__ __forceinline__ f32x4 mma_tile(const _Float16* ahi, const _Float16* alo, int m, int g4, int l15,
                                           const f16x8 (&wh)[KS], const f16x8 (&wl)[KS], float bias) {
+    // two accumulator chains (hi*hi | cross terms) although the un-rescaled split would allow one: shorter dependent
+    // MFMA chains for the waves that have nothing else to issue (the difference measured within noise, ~1 %)
     f32x4 am = f32x4{bias, bias, bias, bias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -51,7 +55,7 @@ __device__ __forceinline__ f32x4 mma_tile(const _Float16* ahi, const _Float16* a
         ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
         ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
     }
-    return am + ac * (1.0f / PW_SPLIT);
+    return am + ac;
 }
 
 // weight image: [n-tile][kstep][lane][hi 8 | lo 8] fp16 (weights.py: pack_linear_f16x3)

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
                 const _Float16 hh = (_Float16)hv;
                 const int idx = a_index<IM_TC>(it, unit);
                 hhi[idx] = hh;
-                hlo[idx] = (_Float16)((hv - (float)hh) * PW_SPLIT);
+                hlo[idx] = (_Float16)(hv - (float)hh);
             }
             hb ^= 1;
             __syncthreads();

@@ -12,19 +12,18 @@ import torch
 
 QK_PAD = 608          # Q / K feature rows padded 582 -> 608 (76 blocks of 8; lh_common.h DQKP)
 KV_PAD_ROWS = 48      # zero rows behind the T+49 rows of kx / vx (include/lookonce_hip.h LH_KV_PAD_ROWS)
-SPLIT_SCALE = 2048.0
 
 
 def unsplit_qk(rows: torch.Tensor, n: int = 582) -> torch.Tensor:
-    """Split-precision q / kx rows [..., 1216] fp16 ([76 blocks][hi 8 | lo 8]) -> fp32 [..., n] (hi + 2^-11 lo)."""
+    """Split-precision q / kx rows [..., 1216] fp16 ([76 blocks][hi 8 | lo 8]) -> fp32 [..., n] (hi + lo)."""
     r = rows.reshape(*rows.shape[:-1], QK_PAD // 8, 2, 8).float()
-    return (r[..., 0, :] + r[..., 1, :] / SPLIT_SCALE).reshape(*rows.shape[:-1], QK_PAD)[..., :n]
+    return (r[..., 0, :] + r[..., 1, :]).reshape(*rows.shape[:-1], QK_PAD)[..., :n]
 
 
 def unsplit_v(rows: torch.Tensor) -> torch.Tensor:
     """Split-precision vx rows [..., 3104] fp16 ([388 quads][hi 4 | lo 4]) -> fp32 [..., 1552]."""
     r = rows.reshape(*rows.shape[:-1], rows.shape[-1] // 8, 2, 4).float()
-    return (r[..., 0, :] + r[..., 1, :] / SPLIT_SCALE).reshape(*rows.shape[:-1], rows.shape[-1] // 2)
+    return (r[..., 0, :] + r[..., 1, :]).reshape(*rows.shape[:-1], rows.shape[-1] // 2)
 
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:
@@ -150,6 +149,12 @@ def pack_linear_f16x3(w: torch.Tensor, unscaled: bool = False) -> torch.Tensor:
     return torch.stack([hi, lo], dim=3).contiguous()
 
 
+def pack_linear_sep(w: torch.Tensor) -> torch.Tensor:
+    """`pack_linear_f16x3` in the separator's split form (lo un-rescaled, lh_split.h); the embedder kernels
+    (lh_embed.hip) still take the rescaled form."""
+    return pack_linear_f16x3(w, unscaled=True)
+
+
 def pack_block(sd: dict, pre: str) -> dict:
     g = lambda k: sd[pre + k].detach()
     out = {}
@@ -178,27 +183,27 @@ def pack_block(sd: dict, pre: str) -> dict:
     # unit 8 w + 2 r + u (PyTorch row g*64 + unit); W_hh additionally split into the two k halves of thread 2n + kh
     n = torch.arange(256, device=iw.device)
     perm = (n & 3) * 64 + (n >> 5) * 8 + ((n >> 3) & 3) * 2 + ((n >> 2) & 1)
-    out["intra_s_wih"] = torch.stack([pack_linear_f16x3(fold_w(g("intra_rnn.weight_ih_l0"), iw)[perm]),
-                                      pack_linear_f16x3(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw)[perm])])
+    out["intra_s_wih"] = torch.stack([pack_linear_sep(fold_w(g("intra_rnn.weight_ih_l0"), iw)[perm]),
+                                      pack_linear_sep(fold_w(g("intra_rnn.weight_ih_l0_reverse"), iw)[perm])])
     out["intra_s_b"] = intra_b[:, perm]
     out["intra_s_whh"] = torch.stack([g("intra_rnn.weight_hh_l0")[perm].reshape(512, 32),
                                       g("intra_rnn.weight_hh_l0_reverse")[perm].reshape(512, 32)])
     # the same layout for the per-sequence inter kernel (lh_inter_matvec, small batches)
-    out["inter_s_wih"] = pack_linear_f16x3(fold_w(g("inter_rnn.weight_ih_l0"), ew)[perm])
+    out["inter_s_wih"] = pack_linear_sep(fold_w(g("inter_rnn.weight_ih_l0"), ew)[perm])
     out["inter_s_b"] = inter_b[perm]
     out["inter_s_whh"] = g("inter_rnn.weight_hh_l0")[perm].reshape(512, 32)
     out["intra_b"] = torch.stack([g("intra_rnn.bias_ih_l0") + g("intra_rnn.bias_hh_l0"),
                                   g("intra_rnn.bias_ih_l0_reverse") + g("intra_rnn.bias_hh_l0_reverse")])
-    out["intra_lin_w"], out["intra_lin_b"] = pack_linear_f16x3(g("intra_linear.weight")), g("intra_linear.bias")
+    out["intra_lin_w"], out["intra_lin_b"] = pack_linear_sep(g("intra_linear.weight")), g("intra_linear.bias")
     # fused kernels: per-direction halves of the bidirectional projection [2 passes][4][2][64][2][8]
-    out["intra_lin_w2"] = torch.stack([pack_linear_f16x3(g("intra_linear.weight")[:, :64].contiguous(), unscaled=True),
-                                       pack_linear_f16x3(g("intra_linear.weight")[:, 64:].contiguous(), unscaled=True)])
+    out["intra_lin_w2"] = torch.stack([pack_linear_sep(g("intra_linear.weight")[:, :64].contiguous()),
+                                       pack_linear_sep(g("intra_linear.weight")[:, 64:].contiguous())])
     out["inter_ln_w"], out["inter_ln_b"] = g("inter_norm.norm.weight"), g("inter_norm.norm.bias")
     out["inter_w"] = pack_lstm(g("inter_rnn.weight_ih_l0"), g("inter_rnn.weight_hh_l0")).unsqueeze(0)
     out["inter_b"] = g("inter_rnn.bias_ih_l0") + g("inter_rnn.bias_hh_l0")
-    out["inter_lin_w"], out["inter_lin_b"] = pack_linear_f16x3(g("inter_linear.weight")), g("inter_linear.bias")
-    out["inter_lin_wu"] = pack_linear_f16x3(g("inter_linear.weight"), unscaled=True)      # fused kernel (lh_inter_block)
-    out["qkv_w"] = pack_linear_f16x3(torch.cat([g("attn_conv_Q.0.weight"), g("attn_conv_K.0.weight"),
+    out["inter_lin_w"], out["inter_lin_b"] = pack_linear_sep(g("inter_linear.weight")), g("inter_linear.bias")
+    out["inter_lin_wu"] = pack_linear_sep(g("inter_linear.weight"))      # fused kernel (lh_inter_block)
+    out["qkv_w"] = pack_linear_sep(torch.cat([g("attn_conv_Q.0.weight"), g("attn_conv_K.0.weight"),
                                                 g("attn_conv_V.0.weight")], 0))
     out["qkv_b"] = torch.cat([g("attn_conv_Q.0.bias"), g("attn_conv_K.0.bias"), g("attn_conv_V.0.bias")])
     out["qkv_slopes"] = torch.cat([g("attn_conv_Q.1.weight"), g("attn_conv_K.1.weight"), g("attn_conv_V.1.weight")])
@@ -207,7 +212,7 @@ def pack_block(sd: dict, pre: str) -> dict:
         padn = (QK_PAD - g(f"attn_conv_{nm}.3.norm.weight").numel()) if nm != "V" else 0
         out[f"ln{nm.lower()}_w"] = torch.nn.functional.pad(g(f"attn_conv_{nm}.3.norm.weight"), (0, padn))
         out[f"ln{nm.lower()}_b"] = torch.nn.functional.pad(g(f"attn_conv_{nm}.3.norm.bias"), (0, padn))
-    out["proj_w"], out["proj_b"] = pack_linear_f16x3(g("attn_concat_proj.0.weight")), g("attn_concat_proj.0.bias")
+    out["proj_w"], out["proj_b"] = pack_linear_sep(g("attn_concat_proj.0.weight")), g("attn_concat_proj.0.bias")
     out["proj_slope"] = g("attn_concat_proj.1.weight")
     out["proj_ln_w"], out["proj_ln_b"] = g("attn_concat_proj.3.norm.weight"), g("attn_concat_proj.3.norm.bias")
     return {k: (v.contiguous() if v.dtype == torch.float16 else v.contiguous().float()) for k, v in out.items()}
@@ -234,13 +239,13 @@ def pack_all(sd: dict, n_blocks: int, prefix: str = "tfgridnet.") -> dict:
     out = {
         "wfb_t": pack_mfma_f32(g("enc.filterbank._filters")[:, 0].t()),      # [192 samples, 194 rows] -> [13][48][64]
         # synthesis filterbank as a split-precision B image: W[n = sample][k = spectrum row], 194 rows padded to 224
-        "wfb_dec": pack_linear_f16x3(torch.nn.functional.pad(g("dec.filterbank._filters")[:, 0].t(), (0, 224 - 194))),   # [12][7][64][2][8]
+        "wfb_dec": pack_linear_sep(torch.nn.functional.pad(g("dec.filterbank._filters")[:, 0].t(), (0, 224 - 194))),   # [12][7][64][2][8]
         "conv_w": pack_mfma_f32(g("conv.0.weight").reshape(-1, 36).t()),     # [36 taps (ch,kt,kf), 64] -> [4][9][64]
         "conv_b": g("conv.0.bias"),
         "emb_w": g("embed_to_feats_proj.0.weight"), "emb_b": g("embed_to_feats_proj.0.bias"),
         "emb_ln_w": g("embed_to_feats_proj.1.weight"), "emb_ln_b": g("embed_to_feats_proj.1.bias"),
         # transposed-conv taps as a split-precision B image: W[n = (kt,kf,o)][k = c], 36 columns padded to 48
-        "deconv_w": pack_linear_f16x3(torch.nn.functional.pad(g("deconv.weight").permute(0, 2, 3, 1).reshape(-1, 36).t(),
+        "deconv_w": pack_linear_sep(torch.nn.functional.pad(g("deconv.weight").permute(0, 2, 3, 1).reshape(-1, 36).t(),
                                                               (0, 0, 0, 12))),   # [3][2][64][2][8]
         "deconv_b": g("deconv.bias"),
     }

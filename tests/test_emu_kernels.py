@@ -152,6 +152,29 @@ def test_attention_tile_modes_multi_tile(emu_net, oracle_cfg_sd):
         lib.call("lh_set_tuning", 4, 2)
 
 
+def test_backend_runs_of_tiles(emu_net, oracle_cfg_sd):
+    """Back end, T = 37 (three 15-frame tiles) with non-zero state: one run of three consecutive tiles per utterance (the
+    second and third tile continue from the first one's partial-product ring and last spectrum), two runs (2 + 1 tiles),
+    and the automatic choice (one run per tile here) must all reproduce the oracle's waveform and next state."""
+    cfg, sd = oracle_cfg_sd
+    lib = emu_net._lib_override
+    B, T = 2, 37
+    d = synth.batch([8, 9], 128 * T + 64)
+    st = O.random_state(cfg, B, 6)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    fo = O.flat_state(so)
+    try:
+        for runs in (1, 2, 0):
+            lib.call("lh_set_tuning", 6, runs)
+            y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+            assert (y - yo).abs().max() < TOL, runs
+            fm = O.flat_state(s2)
+            for k in ("deconv_buf", "istft_buf"):
+                assert (fm[k] - fo[k]).abs().max() < TOL, (runs, k)
+    finally:
+        lib.call("lh_set_tuning", 6, 0)
+
+
 def test_ring_pack_unpack_roundtrip(emu_net):
     """fp32 state -> split-precision history rows -> fp32: hi + 2^-11 lo keeps 22 bits (|err| <= 2^-22 |v| + tiny)."""
     from lookoncetohear_amd.weights import KV_PAD_ROWS, QK_PAD, unsplit_qk, unsplit_v
