@@ -34,10 +34,10 @@ enum {
 /* Contraction arithmetic of the recurrent kernels (argument `mode`):
  *   LH_GEMM_F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32); w_pk = fp32 image  [dirs][4][4][32][64]
  *   LH_GEMM_F16X3 split precision: each fp32 operand = fp16 hi + fp16 lo, three fp16 MFMAs
- *                 (hi*hi, hi*lo, lo*hi) accumulated in fp32 (~22 mantissa bits).  In the RECURRENT kernels
- *                 (lh_ln_lstm_*, lh_intra_block, lh_inter_block) lo = fp16(v - hi) is NOT rescaled (fp16
- *                 subnormals go through the matrix core at full value); every other split-precision image of
- *                 this header stores lo = fp16((v - hi) * 2^11);
+ *                 (hi*hi, hi*lo, lo*hi) accumulated in fp32 (~22 mantissa bits).  Every split-precision image and
+ *                 row of the SEPARATOR entry points stores lo = fp16(v - hi), NOT rescaled (fp16 subnormals go
+ *                 through the matrix core at full value; since ABI 9 — before, only the recurrent kernels did);
+ *                 the embedder entry points (lh_emb_*) keep lo = fp16((v - hi) * 2^11);
  *                 w_pk = fp16 image [dirs][4 waves][4 gates][4 ksteps][64 lanes][hi 8 | lo 8] (lo unscaled) of
  *                 [W_ih * ln_w | W_hh] and b_sum = b_ih + b_hh + W_ih ln_b, rows of both scaled by the exponent factor of their gate (-log2 e for i, f, o;
  *                 -2 log2 e for g: weights.py gate_prescale). The LayerNorm affine is folded into
@@ -50,7 +50,8 @@ int lh_abi_version(void);
 /* Launch-shape tuning knobs (benchmark A/B only; 0 = automatic): key 0 = sequences-per-workgroup/16 of the
  * intra LSTM, key 1 = same for the inter LSTM, key 3 = 0 switches off the issue-priority de-phasing of the two
  * workgroups that share a CU in the fused recurrent kernels (default on), key 4 = query tiles of 16 frames per
- * attention workgroup (1 or 2, default 2). */
+ * attention workgroup (1 or 2, default 2), key 6 = runs of consecutive tiles per utterance in lh_deconv_istft
+ * (0 = automatic: 256 / B). */
 int lh_set_tuning(int key, int value);
 
 /* Validates model_params (reference net.py:21-49 / configs/tsh.json:5-19) against the compiled constants. */
@@ -151,8 +152,9 @@ int lh_linear_res(const float* h, const void* w_pk, const float* bias, const flo
                   int K, lh_stream_t stream);
 
 /* Split-precision activation rows shared by lh_qkv_proj_ln / lh_local_attn / lh_ring_pack / lh_ring_unpack.
- * Every value v is stored as two fp16 numbers  hi = fp16(v), lo = fp16((v - hi) * 2^11)  (4 bytes per element,
- * like fp32; v ~ hi + 2^-11 lo keeps ~22 mantissa bits) in the order the attention MFMA operands consume:
+ * Every value v is stored as two fp16 numbers  hi = fp16(v), lo = fp16(v - hi)  (4 bytes per element,
+ * like fp32; v ~ hi + lo keeps ~22 mantissa bits for |v| >= 2^-3 and an absolute 2^-25 below) in the order the
+ * attention MFMA operands consume:
  *   q   [B*4][T][1216 halves]          per row 76 blocks of 8 features (f*6+e), each [hi 8 | lo 8]; features
  *                                      582..607 are zero
  *   kx  [B*4][T+49+PAD][1216 halves]   same row format; rows 0..48 = history (K_buf), row 49+t = K[t]
@@ -189,7 +191,7 @@ int lh_local_attn(const void* q, const void* kx, const void* vx, float* merged, 
 /* A.3.4  streaming state <-> history rows (tfgridnet_causal.py:553-562).  The reference carries the last 49 K / V
  * rows as fp32 state:  lh_ring_pack writes k_buf [B*4][49][582] / v_buf [B*4][49][1552] into rows 0..48 of kx / vx
  * before lh_qkv_proj_ln;  lh_ring_unpack reads rows T..T+48 (the new history) back into fp32 state tensors
- * (hi + 2^-11 lo, i.e. exactly the values the attention kernel used). */
+ * (hi + lo, i.e. exactly the values the attention kernel used). */
 int lh_ring_pack(const float* k_buf, const float* v_buf, void* kx, void* vx, int B, int T, lh_stream_t stream);
 int lh_ring_unpack(const void* kx, const void* vx, float* k_buf, float* v_buf, int B, int T, lh_stream_t stream);
 

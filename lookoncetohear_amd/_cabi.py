@@ -11,7 +11,7 @@ from ctypes import c_int, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _P, _I = c_void_p, c_int
 # name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
