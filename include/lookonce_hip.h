@@ -62,13 +62,15 @@ int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unu
  * Replaces tfgridnet_causal.py:229-242 (asteroid Encoder conv1d, cat/transpose, conv_buf halo, self.conv).
  *   x            [B][2][n_samples]                 n_samples = 128*T + 64
  *   conv_buf_in  [B][4][2][97]   conv_buf_out same shape (last two frames of the halo-extended spectrum)
- *   wfb_t        fp32 MFMA B image [13 tiles][48 ksteps][64 lanes] of enc.filterbank._filters^T [192 x 194]
- *   wconv_pk     fp32 MFMA B image [4 tiles][9 ksteps][64 lanes] of conv.0.weight as [36 taps (ch,kt,kf)] x [64]
- *                (weights.py pack_mfma_f32);  bconv [64]
+ *   wfb_pk       split-precision B image [13 tiles][6 ksteps][64 lanes][hi 8 | lo 8] of enc.filterbank._filters
+ *                [194 rows -> 208][192 samples]
+ *   wconv_pk     split-precision B image [4 tiles][2 ksteps][64 lanes][hi 8 | lo 8] of conv.0.weight as [64 channels]
+ *                x [K = 64]:  k = 16 kf + 4 kt + ch  (kf, kt < 3, ch < 4), zero elsewhere  (weights.py pack_all);
+ *                bconv [64]
  *   z            [B][T][97][64]  out
  */
-int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* conv_buf_out, const float* wfb_t,
-                    const float* wconv_pk, const float* bconv, float* z, int B, int T, int n_samples,
+int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* conv_buf_out, const void* wfb_pk,
+                    const void* wconv_pk, const float* bconv, float* z, int B, int T, int n_samples,
                     lh_stream_t stream);
 
 /* A.2  speaker gain  g = LayerNorm_6208(W e + b)  stored f-major:  gain[b][f][c] = g[b][c*97+f].

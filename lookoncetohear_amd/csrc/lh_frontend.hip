@@ -1,70 +1,70 @@
 // Front end of the separator: STFT analysis + causal 3x3 conv, and the speaker-gain projection.
 // HBM-streaming kernels (<2 % of the path's FLOPs): one workgroup owns a tile of
-// frames, keeps samples and the spectrum tile in LDS, reads filter rows coalesced over frequency bins.
-#include "lh_common.h"
+// frames, keeps samples and the spectrum tile in LDS and the filterbank in registers.
+#include "lh_split.h"
 
 namespace lh {
 
-// ---- STFT analysis + causal 3x3 conv on fp32 MFMA (exact fp32), persistent workgroups --------------------------
-// A tile = 14 output frames of one utterance (+2 halo frames of the causal conv = 16 STFT frames = one MFMA row
-// tile per microphone).  The analysis filterbank lives in VGPRs for the whole kernel as B fragments (wave w owns
-// filter-row tiles w, w+4, w+8(, 12): 144-192 registers), frames are staged once in LDS as the A image, the
-// spectrum tile [4 ch][16 frames][97 bins] stays in LDS, and the conv is a [97 x 36] x [36 x 64] MFMA contraction
-// per frame whose A operand is gathered straight from the spectrum tile; output rows leave through LDS as
-// 256-byte coalesced stores.
+// ---- STFT analysis + causal 3x3 conv on split-precision fp16 MFMA, persistent workgroups of 8 waves ---------------
+// A tile = 14 output frames of one utterance (+2 halo frames of the causal conv = 16 STFT frames = one MFMA row tile per
+// microphone).  Both contractions run as f16x3 products (v = hi + lo, lh_split.h): the exact-fp32 MFMA version of this
+// kernel spent 38 k matrix cycles per tile and wave (conv 28 k, STFT 10 k) at one wave per SIMD — 0.23 ms per call at
+// B = 32 against an HBM floor of 0.065 ms; this one needs 7.8 k.
+//   * STFT: the 16 frames of a microphone are the A rows (K = 192 samples, fp16 hi/lo images in LDS, 200-half row
+//     stride: conflict-free ds_read_b128); the analysis filterbank lives in VGPRs as B fragments, wave w owns filter-row
+//     tiles w and w + 8 of 13 (96 registers).
+//   * The spectrum tile is written BIN-MAJOR, specT[f + 1][frame * 4 + ch] (rows 0 and 98 = the zero padding of the
+//     f -/+ 1 taps): the 12 taps (kt, ch) of output frame jt at frequency offset kf are then 12 CONTIGUOUS halves of row
+//     f + kf starting at jt * 4, so the conv's A fragments are plain 8-byte-aligned LDS reads — no im2col.  The K axis
+//     is 3 chunks of 16 (12 taps + 4 zero-weight slots that read the next frame's finite values) padded to 64.
+//   * conv: per output frame [97 bins x 64] x [64 x 64 channels]; wave w owns channel tile w & 3 and the row tiles of
+//     its parity; output rows leave through a double-buffered LDS stage as 256-byte coalesced stores, one barrier
+//     per frame.
+constexpr int FE_NTH = 512;
 constexpr int FE_TT = 14;                      // output frames per tile
 constexpr int FE_NJ = 16;                      // STFT frames per tile (2 halo + 14)
-constexpr int FE_KC = NFFT / 4;                // 48: k-chunk of one 16-lane group
-constexpr int FE_KP = FE_KC + 4;               // 52: padded chunk row (13 x 16 B: conflict-free ds_read_b128)
-constexpr int FE_SROW = NF + 3;                // spectrum row: [0]=0 pad, [1..97]=bins, [98]=0 pad, [99] unused
+constexpr int FE_AP = NFFT + 8;                // 200 halves per frame row of the A images
+constexpr int FE_SP = 68;                      // specT row: 16 frames x 4 ch + 4 pad halves (136 B: conflict-free ds_read_b64)
 constexpr int FE_NT = (NK + 15) / 16;          // 13 filter-row tiles (194 -> 208)
+constexpr int FE_KS = NFFT / 32;               // 6 STFT k-steps
 constexpr int FE_OP = C + 4;                   // output staging row
 
-__global__ void __launch_bounds__(256, 1) k_stft_conv_in(const float* __restrict__ x, const float* __restrict__ cbuf_in,
-                                                          float* __restrict__ cbuf_out, const float* __restrict__ wfb_pk,
-                                                          const float* __restrict__ wc_pk, const float* __restrict__ bc,
-                                                          float* __restrict__ z, int B, int T, int n_samples) {
-    __shared__ __attribute__((aligned(16))) float aimg[NMIC * 4 * FE_NJ * FE_KP];
-    __shared__ float spec[2 * NMIC][FE_NJ][FE_SROW];
-    __shared__ __attribute__((aligned(16))) float outs[NF * FE_OP];
+__global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restrict__ x, const float* __restrict__ cbuf_in,
+                                                            float* __restrict__ cbuf_out, const _Float16* __restrict__ wfb_pk,
+                                                            const _Float16* __restrict__ wc_pk, const float* __restrict__ bc,
+                                                            float* __restrict__ z, int B, int T, int n_samples) {
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[NMIC * FE_NJ * FE_AP];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[NMIC * FE_NJ * FE_AP];
+    __shared__ __attribute__((aligned(16))) _Float16 sth[(NF + 2) * FE_SP];
+    __shared__ __attribute__((aligned(16))) _Float16 stl[(NF + 2) * FE_SP];
+    __shared__ __attribute__((aligned(16))) float outs[2][NF * FE_OP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
-    // resident B fragments: filterbank tiles of this wave, conv weights of its 16 output channels
-    float wf[4][FE_KC];
+    // resident B fragments: filterbank tiles wave, wave + 8; conv weights of channel tile wave & 3
+    f16x8 wfh[2][FE_KS], wfl[2][FE_KS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int nt = min(wave + 4 * i, FE_NT - 1);
-#pragma unroll
-        for (int ks = 0; ks < FE_KC; ++ks) wf[i][ks] = wfb_pk[((long)nt * FE_KC + ks) * 64 + lane];
-    }
-    float wcv[9];
-    int aoff[9];                               // spectrum-tile offset of conv tap q = g4*9 + ks -> (ch, kt, kf)
-#pragma unroll
-    for (int ks = 0; ks < 9; ++ks) {
-        wcv[ks] = wc_pk[(wave * 9 + ks) * 64 + lane];
-        const int qq = g4 * 9 + ks, ch = qq / 9, kt = (qq % 9) / 3, kf = qq % 3;
-        aoff[ks] = (ch * FE_NJ + kt) * FE_SROW + kf;
-    }
-    const float cbias = bc[wave * 16 + l15];
+    for (int i = 0; i < 2; ++i) load_w<FE_KS>(wfb_pk, min(wave + 8 * i, FE_NT - 1), lane, wfh[i], wfl[i]);
+    f16x8 wch[2], wcl[2];
+    const int cnt = wave & 3;
+    load_w<2>(wc_pk, cnt, lane, wch, wcl);
+    const float cbias = bc[cnt * 16 + l15];
 
-    for (int i = tid; i < 2 * NMIC * FE_NJ; i += 256) {        // zero the frequency padding columns once
-        float* row = &spec[0][0][0] + i * FE_SROW;
-        row[0] = 0.0f; row[NF + 1] = 0.0f; row[NF + 2] = 0.0f;
-    }
+    for (int i = tid; i < (NF + 2) * FE_SP; i += FE_NTH) { sth[i] = (_Float16)0.f; stl[i] = (_Float16)0.f; }   // pad rows / columns
 
     const int tiles_per_b = (T + FE_TT - 1) / FE_TT;
     for (int tile = blockIdx.x; tile < B * tiles_per_b; tile += gridDim.x) {
         const int b = tile / tiles_per_b;
         const int t0 = (tile % tiles_per_b) * FE_TT;
         const int nt_out = min(FE_TT, T - t0);
-        __syncthreads();                       // previous tile fully consumed (aimg / spec / outs)
+        __syncthreads();                       // previous tile fully consumed (A images / specT / outs)
 
         // stage the 16 frames of both microphones: frame j = samples (t0-2+j)*128 .. +192, 48 float4 each
         {
-            float4 stg[6];
+            constexpr int NLD = NMIC * FE_NJ * 48 / FE_NTH;    // 3
+            float4 stg[NLD];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int e = tid + 256 * i;
+            for (int i = 0; i < NLD; ++i) {
+                const int e = tid + FE_NTH * i;
                 const int m = e / (FE_NJ * 48), j = (e / 48) % FE_NJ, c4 = e % 48;
                 const int t = t0 - 2 + j;
                 stg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -72,82 +72,105 @@ __global__ void __launch_bounds__(256, 1) k_stft_conv_in(const float* __restrict
                     stg[i] = *reinterpret_cast<const float4*>(&x[((long)b * NMIC + m) * n_samples + (long)t * HOP + c4 * 4]);
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int e = tid + 256 * i;
+            for (int i = 0; i < NLD; ++i) {
+                const int e = tid + FE_NTH * i;
                 const int m = e / (FE_NJ * 48), j = (e / 48) % FE_NJ, c4 = e % 48;
-                *reinterpret_cast<float4*>(&aimg[((m * 4 + c4 / 12) * FE_NJ + j) * FE_KP + (c4 % 12) * 4]) = stg[i];
+                const float v[4] = {stg[i].x, stg[i].y, stg[i].z, stg[i].w};
+                f16x4 h4, l4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const _Float16 h = (_Float16)v[q];
+                    h4[q] = h;
+                    l4[q] = (_Float16)(v[q] - (float)h);
+                }
+                const int idx = (m * FE_NJ + j) * FE_AP + c4 * 4;
+                *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
+                *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
             }
         }
         __syncthreads();
 
-        // spectrum: [16 frames x 192] x [192 x 16 filter rows] per (mic, tile)
-#pragma unroll
+        // spectrum: [16 frames x 192] x [192 x 16 filter rows] per (mic, filter tile) -> specT (split), carried halo
+#pragma unroll 1
         for (int m = 0; m < NMIC; ++m) {
-            float av[FE_KC];
-            const float* arow = &aimg[((m * 4 + g4) * FE_NJ + l15) * FE_KP];
+            f32x4 am[2], ac[2];
 #pragma unroll
-            for (int qq = 0; qq < FE_KC / 4; ++qq) {
-                const float4 a4 = *reinterpret_cast<const float4*>(arow + qq * 4);
-                av[qq * 4 + 0] = a4.x; av[qq * 4 + 1] = a4.y; av[qq * 4 + 2] = a4.z; av[qq * 4 + 3] = a4.w;
+            for (int i = 0; i < 2; ++i) { am[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            const bool second = wave + 8 < FE_NT;      // wave-uniform: waves 0..4 own two filter tiles
+#pragma unroll
+            for (int ks = 0; ks < FE_KS; ++ks) {
+                const int idx = (m * FE_NJ + l15) * FE_AP + ks * 32 + g4 * 8;
+                const f16x8 fah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+                const f16x8 fal = *reinterpret_cast<const f16x8*>(&alo[idx]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 0 || second) {
+                        am[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah, wfh[i][ks], am[i], 0, 0, 0);
+                        ac[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah, wfl[i][ks], ac[i], 0, 0, 0);
+                        ac[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal, wfh[i][ks], ac[i], 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nt = wave + 4 * i;
-                if (nt < FE_NT) {              // wave-uniform
-                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 2; ++i) {
+                const int nt = wave + 8 * i;
+                const int k = nt * 16 + l15;                           // filter row: k < 97 re, 97..193 im
+                if (nt < FE_NT && k < NK) {
+                    const int ch = (k / NF) * NMIC + m, f = k % NF;    // channels re_m0, re_m1, im_m0, im_m1
 #pragma unroll
-                    for (int ks = 0; ks < FE_KC; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wf[i][ks], acc, 0, 0, 0);
-                    const int k = nt * 16 + l15;                       // filter row: k < 97 re, 97..193 im
-                    if (k < NK) {
-                        const int ch = (k / NF) * NMIC + m, f = k % NF;    // channels re_m0, re_m1, im_m0, im_m1
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int j = g4 * 4 + r, t = t0 - 2 + j;
-                            float v = acc[r];
-                            if (t < 0) v = cbuf_in[(((long)b * 4 + ch) * 2 + (t + 2)) * NF + f];   // carried halo frames
-                            if (t >= T) v = 0.0f;
-                            spec[ch][j][1 + f] = v;
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = g4 * 4 + r, t = t0 - 2 + j;
+                        float v = am[i][r] + ac[i][r];
+                        if (t < 0) v = cbuf_in[(((long)b * 4 + ch) * 2 + (t + 2)) * NF + f];   // carried halo frames
+                        if (t >= T) v = 0.0f;
+                        const _Float16 h = (_Float16)v;
+                        sth[(f + 1) * FE_SP + j * 4 + ch] = h;
+                        stl[(f + 1) * FE_SP + j * 4 + ch] = (_Float16)(v - (float)h);
+                        // new halo state = the last two frames of the halo-extended spectrum (exact fp32)
+                        if (t >= T - 2 && t < T) cbuf_out[(((long)b * 4 + ch) * 2 + (t - (T - 2))) * NF + f] = v;
                     }
                 }
             }
         }
         __syncthreads();
 
-        // new halo state = last two frames of the halo-extended spectrum (only the last tile holds them)
-        if (t0 + nt_out == T) {
-            for (int i = tid; i < 4 * 2 * NF; i += 256) {
-                const int f = i % NF, r = (i / NF) % 2, ch = i / (2 * NF);
-                cbuf_out[(((long)b * 4 + ch) * 2 + r) * NF + f] = spec[ch][(T - 2 + r) - t0 + 2][1 + f];
-            }
-        }
-
-        // conv: per output frame [97 bins x 36 taps] x [36 x 16 channels of this wave]; A gathered from the tile
+        // conv: per output frame [97 bins x 64 (3 chunks of 12 taps + zero-weight slots)] x [64 x 16 channels of this wave]
+        const int mt0 = wave >> 2;                     // row tiles mt0, mt0 + 2, mt0 + 4 (, 6)
+        const int kf0 = g4 >> 1, cofs = (g4 & 1) * 8;  // k-step 0: chunk kf0; k-step 1: chunk 2 (lanes g4 >= 2 hit zero weights)
         for (int jt = 0; jt < nt_out; ++jt) {
-            f32x4 acc[7];
+            float* ob = outs[jt & 1];
 #pragma unroll
-            for (int mt = 0; mt < 7; ++mt) acc[mt] = f32x4{cbias, cbias, cbias, cbias};
-            const float* sp = &spec[0][0][0] + jt * FE_SROW;
-#pragma unroll
-            for (int ks = 0; ks < 9; ++ks) {
-#pragma unroll
-                for (int mt = 0; mt < 7; ++mt) {
+            for (int i = 0; i < 4; ++i) {
+                const int mt = mt0 + 2 * i;
+                if (mt < 7) {                  // wave-uniform
                     const int f = min(mt * 16 + l15, NF - 1);          // rows >= 97 are dropped below
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sp[aoff[ks] + f], wcv[ks], acc[mt], 0, 0, 0);
+                    const int a0 = (f + kf0) * FE_SP + jt * 4 + cofs, a1 = (f + 2) * FE_SP + jt * 4 + cofs;
+                    f16x8 ah[2], al[2];
+                    auto rd8 = [&](const _Float16* base, int idx) -> f16x8 {     // 8 halves, 8-byte aligned
+                        const f16x4 u = *reinterpret_cast<const f16x4*>(&base[idx]);
+                        const f16x4 w = *reinterpret_cast<const f16x4*>(&base[idx + 4]);
+                        return f16x8{u[0], u[1], u[2], u[3], w[0], w[1], w[2], w[3]};
+                    };
+                    ah[0] = rd8(sth, a0); al[0] = rd8(stl, a0);
+                    ah[1] = rd8(sth, a1); al[1] = rd8(stl, a1);
+                    f32x4 am = f32x4{cbias, cbias, cbias, cbias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], wch[ks], am, 0, 0, 0);
+                        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], wcl[ks], ac, 0, 0, 0);
+                        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], wch[ks], ac, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int fo = mt * 16 + g4 * 4 + r;
+                        if (fo < NF) ob[fo * FE_OP + cnt * 16 + l15] = am[r] + ac[r];
+                    }
                 }
             }
-#pragma unroll
-            for (int mt = 0; mt < 7; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = mt * 16 + g4 * 4 + r;
-                    if (f < NF) outs[f * FE_OP + wave * 16 + l15] = acc[mt][r];
-                }
-            __syncthreads();
+            __syncthreads();                   // frame complete in outs[jt & 1]; the stage of frame jt - 1 is free again
             float* dst = z + (((long)b * T + t0 + jt) * NF) * C;
-            for (int e = tid; e < NF * 16; e += 256)
-                *reinterpret_cast<float4*>(&dst[e * 4]) = *reinterpret_cast<const float4*>(&outs[(e >> 4) * FE_OP + (e & 15) * 4]);
-            __syncthreads();
+            for (int e = tid; e < NF * 16; e += FE_NTH)
+                *reinterpret_cast<float4*>(&dst[e * 4]) = *reinterpret_cast<const float4*>(&ob[(e >> 4) * FE_OP + (e & 15) * 4]);
         }
     }
 }
@@ -203,15 +226,16 @@ __global__ void __launch_bounds__(256) k_embed_ln(const float* __restrict__ raw,
 
 }  // namespace lh
 
-extern "C" int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* conv_buf_out, const float* wfb_t,
-                               const float* wconv_pk, const float* bconv, float* z, int B, int T, int n_samples,
+extern "C" int lh_stft_conv_in(const float* x, const float* conv_buf_in, float* conv_buf_out, const void* wfb_pk,
+                               const void* wconv_pk, const float* bconv, float* z, int B, int T, int n_samples,
                                lh_stream_t stream) {
     using namespace lh;
-    if (!x || !conv_buf_in || !conv_buf_out || !wfb_t || !wconv_pk || !bconv || !z || B <= 0 || T <= 0) return LH_ERR_ARG;
+    if (!x || !conv_buf_in || !conv_buf_out || !wfb_pk || !wconv_pk || !bconv || !z || B <= 0 || T <= 0) return LH_ERR_ARG;
     if (conv_buf_in == conv_buf_out || n_samples != T * HOP + (NFFT - HOP)) return LH_ERR_ARG;
     const int tiles = B * ((T + FE_TT - 1) / FE_TT);
-    hipLaunchKernelGGL(k_stft_conv_in, dim3(tiles < 256 ? tiles : 256), dim3(256), 0, (hipStream_t)stream, x,
-                       conv_buf_in, conv_buf_out, wfb_t, wconv_pk, bconv, z, B, T, n_samples);
+    hipLaunchKernelGGL(k_stft_conv_in, dim3(tiles < 256 ? tiles : 256), dim3(FE_NTH), 0, (hipStream_t)stream, x,
+                       conv_buf_in, conv_buf_out, (const _Float16*)wfb_pk, (const _Float16*)wconv_pk, bconv, z, B, T,
+                       n_samples);
     return check_launch();
 }
 

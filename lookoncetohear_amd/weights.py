@@ -233,14 +233,26 @@ def pack_mfma_f32(w_kn: torch.Tensor, k_pad: int = None) -> torch.Tensor:
     return w[k, n].contiguous()
 
 
+def conv_taps_k64(w: torch.Tensor) -> torch.Tensor:
+    """conv.0.weight [64, 4 ch, 3 kt, 3 kf] -> [64, K = 64] in the front end's K order (lh_frontend.hip): k = 16 kf + 4 kt + ch,
+    the other 28 slots zero (they multiply finite neighbours of the spectrum tile)."""
+    o, ch, kt, kf = w.shape
+    assert (o, ch, kt, kf) == (64, 4, 3, 3)
+    out = torch.zeros(64, 64, dtype=torch.float32, device=w.device)
+    k = (16 * torch.arange(3)[None, None, :] + 4 * torch.arange(3)[None, :, None] + torch.arange(4)[:, None, None]).reshape(-1)
+    out[:, k.to(w.device)] = w.float().reshape(64, -1)
+    return out
+
+
 def pack_all(sd: dict, n_blocks: int, prefix: str = "tfgridnet.") -> dict:
     """sd: state-dict-like mapping with the reference names -> dict of packed fp32 tensors."""
     g = lambda k: sd[prefix + k].detach()
     out = {
-        "wfb_t": pack_mfma_f32(g("enc.filterbank._filters")[:, 0].t()),      # [192 samples, 194 rows] -> [13][48][64]
+        # analysis filterbank as a split-precision B image: W[n = filter row][k = sample], 194 rows padded to 208
+        "wfb_t": pack_linear_sep(torch.nn.functional.pad(g("enc.filterbank._filters")[:, 0], (0, 0, 0, 208 - 194))),  # [13][6][64][2][8]
         # synthesis filterbank as a split-precision B image: W[n = sample][k = spectrum row], 194 rows padded to 224
         "wfb_dec": pack_linear_sep(torch.nn.functional.pad(g("dec.filterbank._filters")[:, 0].t(), (0, 224 - 194))),   # [12][7][64][2][8]
-        "conv_w": pack_mfma_f32(g("conv.0.weight").reshape(-1, 36).t()),     # [36 taps (ch,kt,kf), 64] -> [4][9][64]
+        "conv_w": pack_linear_sep(conv_taps_k64(g("conv.0.weight"))),          # [4][2][64][2][8]
         "conv_b": g("conv.0.bias"),
         "emb_w": g("embed_to_feats_proj.0.weight"), "emb_b": g("embed_to_feats_proj.0.bias"),
         "emb_ln_w": g("embed_to_feats_proj.1.weight"), "emb_ln_b": g("embed_to_feats_proj.1.bias"),
