@@ -84,6 +84,8 @@ def cpu_baseline(sample_clips=4, repeats=2, budget_s=120.0):
     # 32 and 64 threads: the step-serial LSTM / softmax ops stop scaling long before a whole socket, and torch's all-core
     # run of this op mix does not even finish its 1 s warm-up clip in 190 s on the 256-core GPU box (it spends its time
     # in OpenMP barriers), which is how the round-1/2 drivers' bench lines lost their cpu_baseline to the time limit.
+    say = lambda m: print(f"[cpu_baseline {time.perf_counter() - t_start:6.1f} s] {m}", file=sys.stderr, flush=True)
+    say(f"weights + inputs ready, host cores {host}")
     for threads in sorted({min(host, 32), min(host, 64)}):
         if runs and time.perf_counter() - t_start > budget_s / 3:
             break
