@@ -284,7 +284,8 @@ def bench_render(args, dev, rank, world, dist):
     bytes_ = (S1 * N + S1 * 2 * N * 3 + 2 * 2 * N) * 4.0 * B  # src in, events out + 2 reads by the mix, mixture + target out
     valu = flops / (call_ms * 1e-3) / 1e12
     hbm = bytes_ / (call_ms * 1e-3) / 1e9
-    compute_bound = valu / PEAK_FP32_MFMA_TFLOPS > hbm / PEAK_HBM_GBS
+    fft_path = 1024 <= Lh <= 4097                           # lh_render.hip: overlap-save FFT convolution (1/16 of the direct FLOPs)
+    compute_bound = (not fft_path) and valu / PEAK_FP32_MFMA_TFLOPS > hbm / PEAK_HBM_GBS
     cpu = None
     if not args.no_cpu_baseline:
         t1 = time.perf_counter()
@@ -302,8 +303,9 @@ def bench_render(args, dev, rank, world, dist):
                       "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": valu / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                       "note": "fp32 vector FMA (v_pk_fma_f32): same 157 TFLOP/s peak as the fp32 MFMA; not a matrix-core kernel"}
                      if compute_bound else
-                     {"kernel": "lh_render_binaural", "bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                      "frac": hbm / PEAK_HBM_GBS, "traffic": None}),
+                     {"kernel": "lh_render_binaural" + (" (k_fft_conv dominant)" if fft_path else ""), "bound": "hbm",
+                      "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS, "traffic": None,
+                      **({"direct_form_equivalent_tflops": valu} if fft_path else {})}),
         "avg_call_ms": call_ms, "cpu_baseline": cpu, "norm_factor_mean": float(out[2].mean())}))
 
 

@@ -343,6 +343,7 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float __frsqrt_rn(float a) { return 1.0f / sqrtf(a); }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
+static inline void sincospif(float x, float* s, float* c) { const double a = 3.14159265358979323846 * (double)x; *s = (float)sin(a); *c = (float)cos(a); }
 static inline float __ldg(const float* p) { return *p; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -56,8 +56,10 @@ def test_emulated_kernels_match_oracle():
     rr._lib_override = _cabi.Lib(build_emu())
     nf = _check(rr, "cpu", [0, 1], 5003, 200)                   # ragged N, peak below 1: no normalisation
     assert float(nf.max()) < 1.0
-    nf = _check(rr, "cpu", [2], 4500, 3000, loud=4.0, reverb=True)   # Lh > one LDS stage of taps, peak > 1
+    nf = _check(rr, "cpu", [2], 4500, 3000, loud=4.0, reverb=True)   # room-length response: overlap-save FFT path, peak > 1
     assert float(nf.min()) > 1.0
+    _check(rr, "cpu", [4], 9000, 1024)                          # shortest FFT-path response, three output blocks
+    _check(rr, "cpu", [5], 2100, 1000)                          # one tap short of it: direct form, several tap stages
     _check(rr, "cpu", [3], 300, 7)                              # shorter than a tile, tiny filter
     with pytest.raises(ValueError):
         rr.render(torch.zeros(1, 4, 100), torch.zeros(1, 3, 2, 8), torch.ones(1, 4), torch.zeros(1, dtype=torch.int64))
@@ -70,7 +72,10 @@ def test_gpu_render_full_size():
     _cabi.load()
     rr = BinauralRenderer()
     _check(rr, "cuda:0", [0, 1, 2, 3], 80000, 256)              # 5 s clips, HRIR-length responses
-    _check(rr, "cuda:0", [4, 5], 80000, 4096, loud=3.0, reverb=True)   # BRIR-length responses, normalised
+    _check(rr, "cuda:0", [4, 5], 80000, 4096, loud=3.0, reverb=True)   # BRIR-length responses (FFT path), normalised
+    _check(rr, "cuda:0", [9], 80000, 4097, reverb=True)         # longest FFT-path response
+    _check(rr, "cuda:0", [10], 50000, 5000, reverb=True)        # longer than that: direct form with tap stages
+    _check(rr, "cuda:0", [11], 80000, 1023)                     # just below the FFT path
     _check(rr, "cuda:0", [6], 12345, 33)
     sc, srcs, rirs, gains, tgt = _batch([7, 8], 80000, 256)
     a = rr.render(srcs.cuda(), rirs.cuda(), gains.cuda(), tgt.cuda())
