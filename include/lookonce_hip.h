@@ -49,8 +49,8 @@ int lh_abi_version(void);
 
 /* Launch-shape tuning knobs (benchmark A/B only; 0 = automatic): key 0 = sequences-per-workgroup/16 of the
  * intra LSTM, key 1 = same for the inter LSTM, key 3 = 0 switches off the issue-priority de-phasing of the two
- * workgroups that share a CU in the fused recurrent kernels (default on), key 4 = query tiles of 16 frames per
- * attention workgroup (1 or 2, default 2), key 6 = runs of consecutive tiles per utterance in lh_deconv_istft
+ * workgroups that share a CU in the fused recurrent kernels (default on), key 4 = query frames per
+ * attention workgroup (1 / 2 = tiles of 16, 3 = 40 frames in three tiles; 0 = automatic), key 6 = runs of consecutive tiles per utterance in lh_deconv_istft
  * (0 = automatic: 256 / B). */
 int lh_set_tuning(int key, int value);
 

@@ -33,19 +33,21 @@ constexpr int AT_PKS = 3;                     // 32-key steps in P.V (96 >= 32 +
 constexpr int AT_PP = AT_PKS * 32 + 8;        // P row stride in halves (208 bytes: conflict-free ds_read_b128)
 constexpr int AT_CG = (DV + 63) / 64;         // 25 column groups of 64 V columns
 
-template <int MQ, int RING>
+template <int MQ, int RING, int TQ = 16 * MQ>
 __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restrict__ q, const _Float16* __restrict__ kx,
                                                        const _Float16* __restrict__ vx, float* __restrict__ merged,
                                                        int BH, int T, int ntt) {
-    constexpr int TQ = 16 * MQ;                // query frames per workgroup
-    constexpr int NKEYS = TQ + HIST;           // key rows they can see (65 / 81)
+    // TQ query frames per workgroup in MQ MFMA row tiles (TQ = 16 MQ, or 40 in 3 tiles: 625 frames are then 16 tiles
+    // per (batch, head), 2048 workgroups at batch 32 = exactly four rounds of the 512 resident workgroups)
+    constexpr int NKEYS = TQ + HIST;           // key rows they can see (65 / 81 / 89)
     constexpr int NKT = (NKEYS + 15) / 16;     // key tiles in the score phase (5 / 6)
     constexpr int NK = NKT * 16;
-    constexpr int ND = 5;                      // key tiles per query tile: nt = mq .. mq+4
-    static_assert(NKEYS <= AT_PKS * 32 && NKT == MQ + ND - 1 && NK - 1 <= HIST + KV_PAD, "tile geometry");
-    __shared__ float sp[4][TQ][NK];
-    __shared__ __attribute__((aligned(16))) _Float16 ph[TQ][AT_PP];
-    __shared__ __attribute__((aligned(16))) _Float16 pl[TQ][AT_PP];
+    constexpr int ND = 5;                      // key tiles per query tile: nt = mq .. mq+4 (as far as they exist)
+    constexpr int NB = ND * 16;                // band width stored per query row
+    static_assert(TQ <= 16 * MQ && TQ > 16 * (MQ - 1) && NKEYS <= AT_PKS * 32 && NK - 1 <= HIST + KV_PAD, "tile geometry");
+    __shared__ float sp[4][TQ][NB];            // per-wave partial scores, band-relative columns (d, l15)
+    __shared__ __attribute__((aligned(16))) _Float16 ph[16 * MQ][AT_PP];
+    __shared__ __attribute__((aligned(16))) _Float16 pl[16 * MQ][AT_PP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
     // XCD-aware placement: the tiles of (batch, head) bh all run on XCD bh % 8
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
             for (int mq = 0; mq < MQ; ++mq)
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
+                    if (mq + d >= NKT) continue;       // compile-time: the last tile of a 40-frame workgroup sees 4 key tiles
                     const Frag& kf = sk[mq + d];
                     am[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].h, kf.h, am[mq][d], 0, 0, 0);
                     am[mq][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sq[mq].h, kf.l, am[mq][d], 0, 0, 0);
@@ -108,8 +111,10 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
 #pragma unroll
             for (int d = 0; d < ND; ++d)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sp[wave][mq * 16 + g4 * 4 + r][(mq + d) * 16 + l15] = am[mq][d][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mq * 16 + g4 * 4 + r;
+                    if (TQ == 16 * MQ || row < TQ) sp[wave][row][d * 16 + l15] = am[mq][d][r];
+                }
     }
     __syncthreads();
 
@@ -119,14 +124,16 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
         constexpr int NU = AT_PKS * 2;            // 6 column slots of 16 per thread (96 key columns)
 #pragma unroll
         for (int pass = 0; pass < MQ; ++pass) {
-            const int i = pass * 16 + (tid >> 4), sub = tid & 15;
+            const int ir = pass * 16 + (tid >> 4), sub = tid & 15;
+            const int i = min(ir, TQ - 1);         // rows past TQ (40-frame tiles) recompute row TQ-1 and store nothing
             float sv[NU];
             float mx = -3.0e38f;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int n = sub + 16 * u, j = n - i;
+                const int c = n - pass * 16;           // band-relative column; in [0, 65) whenever j is in the window
                 float s = -3.0e38f;
-                if (j >= 0 && j < WIN) s = (sp[0][i][n] + sp[1][i][n] + sp[2][i][n] + sp[3][i][n]) * scale;
+                if (j >= 0 && j < WIN) s = (sp[0][i][c] + sp[1][i][c] + sp[2][i][c] + sp[3][i][c]) * scale;
                 sv[u] = s;
                 mx = fmaxf(mx, s);
             }
@@ -145,8 +152,10 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
             for (int u = 0; u < NU; ++u) {
                 const float p = sv[u] * inv;           // exactly 0 outside the band
                 const _Float16 h = (_Float16)p;
-                ph[i][sub + 16 * u] = h;
-                pl[i][sub + 16 * u] = (_Float16)(p - (float)h);
+                if (TQ == 16 * MQ || ir < TQ) {
+                    ph[ir][sub + 16 * u] = h;
+                    pl[ir][sub + 16 * u] = (_Float16)(p - (float)h);
+                }
             }
         }
     }
@@ -226,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int t = t0 + mq * 16 + g4 * 4 + r;
-                        if (t < T)      // head-major slab [b][t][hd][f][v]: one head's frame is 6208 contiguous bytes
+                        if (t < T && (TQ == 16 * MQ || mq * 16 + g4 * 4 + r < TQ))      // head-major slab [b][t][hd][f][v]: one head's frame is 6208 contiguous bytes
                             *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * NH + hd) * DV + col]) =
                                 make_float4(am[mq][0][r], am[mq][1][r], am[mq][2][r], am[mq][3][r]);
                     }
@@ -309,9 +318,10 @@ __global__ void __launch_bounds__(256) k_ring_unpack(const _Float16* __restrict_
     }
 }
 
-static int g_attn_mq = 2;              // query tiles of 16 frames per workgroup (lh_set_tuning key 4: 1 or 2)
+static int g_attn_mq = 0;              // lh_set_tuning key 4: 0 = automatic, 1 / 2 = query tiles of 16 frames per workgroup,
+                                       // 3 = 40 frames in three tiles
 int attn_set_mq(int v) {
-    if (v != 1 && v != 2) return LH_ERR_ARG;
+    if (v < 0 || v > 3) return LH_ERR_ARG;
     g_attn_mq = v;
     return LH_OK;
 }
@@ -324,18 +334,24 @@ extern "C" int lh_local_attn(const void* q, const void* kx, const void* vx, floa
     if (!q || !kx || !vx || !merged || B <= 0 || T <= 0) return LH_ERR_ARG;
     const int BH = B * NH;
     const int bh8 = (BH + 7) / 8 * 8;
-    // a single query tile when the clip is that short (streaming: T = 1) — the second tile would be all padding
-    // two query tiles per workgroup share every K / V row they load (25 instead of 44 KB of L2 traffic per query;
-    // measured 0.36 against 0.43 ms at B = 32); a single tile when the clip is that short (streaming: T = 1).
-    // The two-tile kernel runs a two-deep V ring: a three-deep one (228 registers since the single-accumulator split)
-    // measured 3 % slower.
-    const int mq = T <= 16 ? 1 : g_attn_mq;
-    const int ntt = (T + 16 * mq - 1) / (16 * mq);
+    // Query frames per workgroup: one 16-frame tile when the clip is that short (streaming: T = 1); two tiles share
+    // every K / V row they load (25 instead of 44 KB of L2 traffic per query; 0.36 against 0.43 ms at B = 32); 40 frames
+    // in three tiles once the launch has more workgroups than the 512 resident ones (12 % fewer K / V rows per query,
+    // and at B = 32, T = 625 exactly four rounds of workgroups instead of five: 0.343 against 0.356 ms) — below that a
+    // launch is latency-bound and the shorter workgroup wins.  The V ring is two-deep: a three-deep one (228 registers
+    // since the single-accumulator split) measured 3 % slower.
+    int mq = g_attn_mq;
+    if (T <= 16) mq = 1;
+    else if (mq == 0) mq = (long)bh8 * ((T + 31) / 32) > 512 ? 3 : 2;
+    const int tq = mq == 3 ? 40 : 16 * mq;
+    const int ntt = (T + tq - 1) / tq;
     // latency-bound launches (a handful of workgroups): split the V columns of a tile over 7 workgroups
     const dim3 grid(bh8 * ntt, bh8 * ntt <= 64 ? 7 : 1);
     const _Float16 *qh = (const _Float16*)q, *kh = (const _Float16*)kx, *vh = (const _Float16*)vx;
     if (mq == 1)
         hipLaunchKernelGGL((k_local_attn<1, 3>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
+    else if (mq == 3)
+        hipLaunchKernelGGL((k_local_attn<3, 2, 40>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
     else
         hipLaunchKernelGGL((k_local_attn<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
     return check_launch();

@@ -140,16 +140,24 @@ def test_attention_tile_modes_multi_tile(emu_net, oracle_cfg_sd):
     yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
     fo = O.flat_state(so)
     try:
-        for mode in (1, 2):
+        for mode in (1, 2, 3):                               # 3 = 40-frame tiles in three MFMA row tiles (one ragged tile here)
             lib.call("lh_set_tuning", 4, mode)
             y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
             assert (y - yo).abs().max() < TOL, mode
             fm = O.flat_state(s2)
             for k in fo:
                 assert fm[k].shape == fo[k].shape and (fm[k] - fo[k]).abs().max() < TOL, (mode, k)
-        assert lib.raw("lh_set_tuning")(4, 3) == 1           # LH_ERR_ARG
+        assert lib.raw("lh_set_tuning")(4, 4) == 1           # LH_ERR_ARG
+        # T = 85: three 40-frame tiles (t0 = 0, 40, 80; the last one 5 frames), dead rows 40..47 of every third row tile
+        T2 = 85
+        d2 = synth.batch([11], 128 * T2 + 64)
+        st2 = O.random_state(cfg, B, 7)
+        yo2, _ = O.predict(cfg, sd, d2["mixture"], d2["embedding_gt"][:, 0], O.clone_state(st2), pad=False)
+        lib.call("lh_set_tuning", 4, 3)
+        y2, _ = emu_net.predict(d2["mixture"], d2["embedding_gt"][:, 0], O.clone_state(st2), pad=False)
+        assert (y2 - yo2).abs().max() < TOL
     finally:
-        lib.call("lh_set_tuning", 4, 2)
+        lib.call("lh_set_tuning", 4, 0)
 
 
 def test_backend_runs_of_tiles(emu_net, oracle_cfg_sd):
