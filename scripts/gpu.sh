@@ -54,6 +54,7 @@ profile)            # rocprofv3 kernel stats + PMC passes (separate runs) of the
         python $R/scripts/rocpd_summary.py /tmp/prof_$C/r1_results.db $R/gpurun_out/pmc_$C.csv --pmc
     done
     python $R/scripts/make_pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv 32 $R/gpurun_out/pmc_traffic.json
+    [ "${LITE:-0}" = "1" ] && { cd $R; head -12 gpurun_out/kernel_stats.csv; exit 0; }      # LITE=1: stats + traffic passes only
     timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_sq -o r1 -- $P > $R/gpurun_out/prof_sq.log 2>&1; echo "rocprof sq rc=$?"
     python $R/scripts/rocpd_summary.py /tmp/prof_sq/r1_results.db $R/gpurun_out/pmc_sq.csv --pmc
     timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM -d /tmp/prof_sq2 -o r1 -- $P > $R/gpurun_out/prof_sq2.log 2>&1; echo "rocprof sq2 rc=$?"
