@@ -19,12 +19,18 @@ constexpr int BE_NT = 512;                // threads per workgroup (8 waves, two
 constexpr int BE_TT = 15;                 // output frames per tile
 constexpr int BE_NJ = BE_TT + 1;          // Sx frames t0 .. t0+15 (one MFMA row tile per source)
 constexpr int BE_NP = 36;                 // partial-product columns (kt,kf,o); the B image pads them to 48
-constexpr int BE_PP = BE_NP + 1;          // P row stride (odd: conflict-free gather)
+constexpr int BE_PP = 40;                 // P row stride: 16-byte aligned rows, the gather reads the 4 outputs of a tap as one float4
 constexpr int BE_SK = 7;                  // synthesis k-steps: 194 spectrum rows -> 224
 constexpr int BE_SA = BE_SK * 4 * BE_NJ * 8;   // halves per source in the Sx A image
 constexpr int BE_FP = NFFT + 4;           // synthesis frame staging row
 constexpr int BE_NLD = (NF * 16 + BE_NT - 1) / BE_NT;   // float4 per thread and frame (4)
 constexpr int BE_RING = 4;                // input frames in flight per workgroup
+#if defined(LH_PROBE_TRACE)              // timing probe build only (scripts/probe_trace.py --backend): stamps of workgroup 3, tile 2 of its run
+__device__ unsigned long long lh_be_trace_buf[32];
+#define BE_STAMP(k) do { if (blockIdx.x == 3 && tid == 0 && tk == k0_ + 2) lh_be_trace_buf[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BE_STAMP(k) do { } while (0)
+#endif
 
 // grid = persistent (<= 256), block 512
 __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict__ y, const float* __restrict__ dbuf_in,
@@ -37,7 +43,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * FR_A];                 // A images of two input frames
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * FR_A];
     // partial products of 4 frames; bin f sits in row f + 1, rows 0 and 98 stay zero (the f -/+ 1 taps of the edge bins)
-    __shared__ float pring[4][NF + 2][BE_PP];
+    __shared__ __attribute__((aligned(16))) float pring[4][NF + 2][BE_PP];
     __shared__ __attribute__((aligned(16))) _Float16 sxh[NSRC * BE_SA];             // A image of the 16 spectra
     __shared__ __attribute__((aligned(16))) _Float16 sxl[NSRC * BE_SA];
     // synthesis frames: only live after the frame loop, in the space of the (then dead) hi A images
@@ -71,7 +77,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     const long L = (long)HOP * T;
     // flat loop over the tiles of this workgroup's runs: runs blockIdx.x, blockIdx.x + gridDim.x, ...; inside a run the
     // tiles follow each other
-    int run = blockIdx.x, tk = 0, k1 = 0;             // tk == k1: fetch the next run
+    int run = blockIdx.x, tk = 0, k1 = 0, k0_ = 0;    // tk == k1: fetch the next run (k0_: its first tile, probe only)
     for (;;) {
         bool first = false;
         if (tk == k1) {
@@ -80,6 +86,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             tk = (int)((long)tiles_per_b * rb0 / runs_per_b);
             k1 = (int)((long)tiles_per_b * (rb0 + 1) / runs_per_b);
             first = true;
+            k0_ = tk;
         }
         const int b = run / runs_per_b;
         {
@@ -91,6 +98,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
         // call with the hoisted addresses and spills, 0.26 ms with the indices recomputed per tile)
         const int tv = tid + (tk >> 30);
         __syncthreads();
+        BE_STAMP(0);
 
         // one spectrum value -> row jd of source s's A image
         auto put_sx = [&](int jd, int s, int k, float v) {
@@ -112,6 +120,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             }
             __syncthreads();                          // row 15 is rewritten by this tile's last frame
         }
+        BE_STAMP(17);
 
         // input frames t0-3 .. t0+nt_out-1 ; after frame fr has been multiplied, output frame td = fr is complete
         float4 stg[BE_RING][BE_NLD];
@@ -127,25 +136,39 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                 }
             }
         };
-        auto load_frame_y = [&](int fr, float4 (&dst)[BE_NLD]) {          // fr >= 0: a frame of y
+        // fr >= 0: a frame of y.  Per-thread element offsets once per tile, the frame's base is wave-uniform: the load issue
+        // of a frame pair took 1300 cycles when every float4 recomputed its 64-bit index
+        unsigned eoff[BE_NLD];
 #pragma unroll
-            for (int i = 0; i < BE_NLD; ++i) {
-                const int e = min(tv + BE_NT * i, NF * 16 - 1), f = e >> 4, c4 = e & 15;
-                dst[i] = *reinterpret_cast<const float4*>(&y[(((long)b * T + fr) * NF + f) * C + c4 * 4]);
-            }
+        for (int i = 0; i < BE_NLD; ++i) eoff[i] = (unsigned)min(tv + BE_NT * i, NF * 16 - 1) * 16u;
+        const char* yb = reinterpret_cast<const char*>(y) + (long)b * T * NF * C * 4;
+        auto load_frame_y = [&](int fr, float4 (&dst)[BE_NLD]) {
+            const char* base = yb + (long)fr * (NF * C * 4);
+#pragma unroll
+            for (int i = 0; i < BE_NLD; ++i) dst[i] = *reinterpret_cast<const float4*>(base + eoff[i]);
         };
         const int fr_first = cont ? t0 : max(t0 - 3, -2);   // frames below -2 do not exist (their taps see nothing)
         const int fr_end = t0 + nt_out;
+        BE_STAMP(18);
         // BE_RING frames in flight per workgroup: with a single one the loop ran at one HBM round trip per frame
+        if (fr_first >= 0) {                          // no carried halo frame in the first ring turn: four straight loads
 #pragma unroll
-        for (int u = 0; u < BE_RING; ++u)
-            if (fr_first + u < fr_end) load_frame(fr_first + u, stg[u]);
+            for (int u = 0; u < BE_RING; ++u) load_frame_y(min(fr_first + u, T - 1), stg[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < BE_RING; ++u)
+                if (fr_first + u < fr_end) load_frame(fr_first + u, stg[u]);
+        }
+        BE_STAMP(1);
         for (int fbase = fr_first; fbase < fr_end; fbase += BE_RING) {
+            BE_STAMP(2 + (fbase - fr_first) / BE_RING);
 #pragma unroll
           for (int u = 0; u < BE_RING; u += 2) {
             const int fr = fbase + u;                 // this iteration: frames fr and fr + 1 (the second may not exist)
             if (fr >= fr_end) break;
             const bool two = fr + 1 < fr_end;
+            const bool tr_it = fbase == fr_first + BE_RING && u == 0;      // probe only
+            if (tr_it) BE_STAMP(11);
             // stage the frames into the two A images, refill their ring slots
 #pragma unroll
             for (int i = 0; i < BE_NLD; ++i) {
@@ -156,52 +179,97 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                 }
             }
             __syncthreads();
+            if (tr_it) BE_STAMP(12);
+            // Refill the two ring slots UNCONDITIONALLY (frame index clamped to the clip: a frame past the tile is loaded
+            // and never used): with the loads under `if (fr + BE_RING < fr_end)` the compiler cannot count the outstanding
+            // loads at the loop head and waits for vmcnt(0) there, i.e. for the loads it has just issued — every pair of
+            // frames then paid a full HBM round trip (s_memtime trace: 8.5 k cycles per pair against ~3 k of work).
             // (frames fr + BE_RING >= fr_first + 4 >= 2: never the carried halo frames)
-            if (fr + BE_RING < fr_end) load_frame_y(fr + BE_RING, stg[u]);
-            if (fr + 1 + BE_RING < fr_end) load_frame_y(fr + 1 + BE_RING, stg[u + 1]);
+            // The second slot is refilled behind the products: all eight waves issuing both frames' loads at the same point
+            // queued 2000 cycles on the CU's vector-memory path.
+            load_frame_y(min(fr + BE_RING, T - 1), stg[u]);
+            if (tr_it) BE_STAMP(15);
 
-            // P[fr + q] = Y[fr + q] (97 x 64) * Wd (64 x 48): 2 x 21 (row tile, column tile) products over the 8 waves
-            for (int p = wave; p < (two ? 42 : 21); p += 8) {
-                const int q = p >= 21, pp = p - 21 * q, mt = pp / 3, nt = pp % 3;
-                const int slot = (fr + q + 4) & 3;    // fr >= -2
-                f16x8 wh[2], wl[2];
+            // P[fr + q] = Y[fr + q] (97 x 64) * Wd (64 x 48).  Wave w < 7 owns row tile w of both frames: its A fragments
+            // are read once and feed the three column tiles, six independent accumulator chains per wave.  (Spreading
+            // the 42 (row tile, column tile) products one by one over the 8 waves re-read A and W per product and ran
+            // them strictly one after the other: 770 cycles per product in the s_memtime trace, 55 % of the frame loop.)
+            if (wave < 7) {
+                const int mt = wave;
+                f16x8 ah[2][2], al[2][2];                 // [frame][k-step]
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    wh[ks] = *reinterpret_cast<const f16x8*>(&wds[((nt * 2 + ks) * 64 + lane) * 16]);
-                    wl[ks] = *reinterpret_cast<const f16x8*>(&wds[((nt * 2 + ks) * 64 + lane) * 16 + 8]);
-                }
-                const f32x4 acc = mma_tile<FR_RP, 2>(ahi + q * FR_A, alo + q * FR_A, mt, g4, l15, wh, wl, 0.f);
-                const int col = nt * 16 + l15;
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = mt * 16 + g4 * 4 + r;
-                    if (f < NF && col < BE_NP) pring[slot][f + 1][col] = acc[r];
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int idx = q * FR_A + a_slot<FR_RP>(ks * 4 + g4, mt * 16 + l15);
+                        ah[q][ks] = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+                        al[q][ks] = *reinterpret_cast<const f16x8*>(&alo[idx]);
+                    }
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {          // each W fragment is read once and serves both frames
+                    f32x4 am[2], ac[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { am[q] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const f16x8 wh = *reinterpret_cast<const f16x8*>(&wds[((nt * 2 + ks) * 64 + lane) * 16]);
+                        const f16x8 wl = *reinterpret_cast<const f16x8*>(&wds[((nt * 2 + ks) * 64 + lane) * 16 + 8]);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {      // (the second frame's image is stale, never stored, when !two)
+                            am[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q][ks], wh, am[q], 0, 0, 0);
+                            ac[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q][ks], wl, ac[q], 0, 0, 0);
+                            ac[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q][ks], wh, ac[q], 0, 0, 0);
+                        }
+                    }
+                    const int col = nt * 16 + l15;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q == 1 && !two) break;
+                        const int slot = (fr + q + 4) & 3;    // fr >= -2
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = mt * 16 + g4 * 4 + r;
+                            if (f < NF && col < BE_NP) pring[slot][f + 1][col] = am[q][r] + ac[q][r];
+                        }
+                    }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            load_frame_y(min(fr + 1 + BE_RING, T - 1), stg[u + 1]);
+            if (tr_it) BE_STAMP(16);
             __syncthreads();
+            if (tr_it) BE_STAMP(13);
 
             // output frames td = fr, fr + 1: D[o][f] = b[o] + sum_{kt,kf} P[td-kt][f+1-kf][(kt*3+kf)*4 + o]
-            for (int i = tv; i < (two ? 2 : 1) * 4 * NF; i += BE_NT) {
-                const int q = i >= 4 * NF, ii = i - 4 * NF * q;
+            for (int i = tv; i < (two ? 2 : 1) * NF; i += BE_NT) {      // one (frame, bin) per thread: its 4 outputs together
+                const int q = i >= NF, f = i - NF * q;
                 const int td = fr + q;
                 if (td < t0 - 1 || td < 0) continue;
                 const int jd = td + 1 - t0;           // Sx frame index inside the tile
-                const int o = ii & 3, f = ii >> 2;
-                float v = bias4[o];
+                float4 v = make_float4(bias4[0], bias4[1], bias4[2], bias4[3]);
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
                     const int ps = (td - kt + 4) & 3;         // td >= 0, so frame td - kt >= -2 exists (halo or zero state)
 #pragma unroll
-                    for (int kf = 0; kf < 3; ++kf) v += pring[ps][f + 2 - kf][(kt * 3 + kf) * 4 + o];   // guard rows: no bounds
+                    for (int kf = 0; kf < 3; ++kf) {          // guard rows: no bounds
+                        const float4 pv = *reinterpret_cast<const float4*>(&pring[ps][f + 2 - kf][(kt * 3 + kf) * 4]);
+                        v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+                    }
                 }
-                const int s = o >> 1, k = (o & 1) * NF + f;
-                put_sx(jd, s, k, v);
-                if (td == T - 1) ibuf_out[((long)b * NSRC + s) * NK + k] = v;      // new carried spectrum (exact fp32)
+                const float vo[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int s = o >> 1, k = (o & 1) * NF + f;
+                    put_sx(jd, s, k, vo[o]);
+                    if (td == T - 1) ibuf_out[((long)b * NSRC + s) * NK + k] = vo[o];      // new carried spectrum (exact fp32)
+                }
             }
+            if (tr_it) BE_STAMP(14);
             // the next iteration's staging barrier orders these pring reads before their slots are overwritten
           }
         }
         __syncthreads();
+        BE_STAMP(8);
 
         // new carried conv halo (last tile only)
         if (t0 + nt_out == T) {
@@ -230,6 +298,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             }
         }
         __syncthreads();
+        BE_STAMP(9);
 
         // overlap-add: output frame t (samples 128t..128t+127) = fr[t+1][0:128] + fr[t][128:192]
         for (int i = tid; i < nt_out * NSRC * HOP; i += BE_NT) {
@@ -239,8 +308,13 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             wave_out[((long)b * NSRC + s) * L + (long)(t0 + jt) * HOP + n] = v;
         }
         __syncthreads();
-        // frs lived in the hi A images: their pad rows (97..111 feed dropped outputs) must hold finite numbers again
-        for (int i = tid; i < 2 * FR_A; i += BE_NT) ahi[i] = (_Float16)0.f;
+        // frs lived in the hi A images: their pad rows (97..111 feed dropped outputs) must hold finite numbers again —
+        // only those: the 97 real rows are rewritten by the staging of the next frames
+        for (int i = tid; i < 2 * (FR_RP - NF) * 16; i += BE_NT) {
+            const int img = i / ((FR_RP - NF) * 16), e = i % ((FR_RP - NF) * 16);
+            *reinterpret_cast<f16x4*>(&ahi[img * FR_A + a_index<FR_RP>(NF + (e >> 4), (e & 15) * 4)]) = f16x4{0, 0, 0, 0};
+        }
+        BE_STAMP(10);
         }
         if (++tk == k1) run += gridDim.x;
     }
@@ -254,6 +328,12 @@ int backend_set_runs(int v) {
 }
 
 }  // namespace lh
+
+#if defined(LH_PROBE_TRACE)
+extern "C" int lh_probe_be_trace_read(unsigned long long* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::lh_be_trace_buf), sizeof(lh::lh_be_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out,
                                const float* istft_buf_in, float* istft_buf_out, const void* wdec_pk,

@@ -41,3 +41,17 @@ for w, name in enumerate(["workgroup 7 (first round)", "workgroup n-9 (last roun
     print("   segments median: rows %.1f  mfma %.1f  cells %.1f  barrier %.1f" %
           (np.median(seg[:, 0]), np.median(seg[:, 1]), np.median(seg[:, 2]), np.median(bar)))
     print("   first 12 steps:", step[:12].tolist())
+
+# back end (k_deconv_istft): stamps of workgroup 3, third tile of its run
+bb = np.zeros(32, dtype=np.uint64)
+if lib.raw("lh_probe_be_trace_read")(bb.ctypes.data_as(ctypes.c_void_p)) == 0:
+    b = bb.astype(np.int64)
+    names = ["tile start -> ring primed", "primed -> loop", "frames 0-3", "frames 4-7", "frames 8-11", "frames 12-14",
+             "loop end -> barrier", "", "halo + synthesis", "overlap-add + re-zero"]
+    seq = [0, 1, 2, 3, 4, 5, 8, 9, 10]
+    print("back end tile (cycles):", {f"{seq[i]}->{seq[i+1]}": int(b[seq[i + 1]] - b[seq[i]]) for i in range(len(seq) - 1)},
+          "total", int(b[10] - b[0]))
+    print("one pair of frames: stage + barrier", int(b[12] - b[11]), " loads issued + 42 tile products + barrier", int(b[13] - b[12]),
+          " gather + spectrum split", int(b[14] - b[13]), "| inside the product phase: load issue", int(b[15] - b[12]),
+          "wave 0's products", int(b[16] - b[15]), "barrier wait", int(b[13] - b[16]))
+    print("tile start: Sx copy + barrier", int(b[17] - b[0]), " setup", int(b[18] - b[17]), " ring priming (16 loads issued)", int(b[1] - b[18]))
