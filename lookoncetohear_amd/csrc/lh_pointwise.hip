@@ -182,6 +182,13 @@ constexpr int Y_K0 = NH * YQS;
 constexpr int Y_V0 = 2 * NH * YQS;
 constexpr int Y_N = Y_V0 + NH * DV;        // 11136 floats
 
+#if defined(LH_PROBE_TRACE)               // timing probe build only (scripts/probe_trace.py): workgroup 5, its 4th frame
+__device__ unsigned long long lh_qkv_trace_buf[16];
+#define QKV_STAMP(k) do { if (blockIdx.x == 5 && tid == 0 && fr == 5 + 3 * (int)gridDim.x) lh_qkv_trace_buf[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QKV_STAMP(k) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slopes,
                                                      const float* __restrict__ lnq_w, const float* __restrict__ lnq_b,
@@ -224,8 +231,10 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     const int krow0 = ring_pos ? (int)((unsigned)*ring_pos % (unsigned)WIN) : HIST;   // unsigned: never before the ring
     for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
         const int b = fr / T, t = fr % T;
+        QKV_STAMP(0);
         frame_store(ahi, alo, tid, stg);
         __syncthreads();                      // image complete; also orders the previous frame's reads of `yf`
+        QKV_STAMP(1);
         if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
         // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check
@@ -248,7 +257,9 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
 #pragma unroll 1
         for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{});
         row_tile(NF / 16, std::true_type{});
+        QKV_STAMP(2);
         __syncthreads();
+        QKV_STAMP(3);
 
         // per-head LayerNorm: wave w normalises head w of Q, K and V and writes the split-precision rows
         const int hd = wave;
@@ -274,6 +285,7 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
             lq.store<0>(rq, qrow, ln);
             lk.store<0>(rk, krow, ln);
         }
+        QKV_STAMP(4);
         {
             HeadLN<DV, DV / 8> lv;
             lv.load_affine(lnv_w, lnv_b, ln);
@@ -283,8 +295,16 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
             const float rv = rsqrtf(wave_sum(vv) * (1.0f / DV) + LN_EPS);
             lv.store<1>(rv, vrow, ln);
         }
+        QKV_STAMP(5);
     }
 }
+#if defined(LH_PROBE_TRACE)
+}  // namespace lh
+extern "C" int lh_probe_qkv_trace_read(unsigned long long* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::lh_qkv_trace_buf), sizeof(lh::lh_qkv_trace_buf)) == hipSuccess ? 0 : 1;
+}
+namespace lh {
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // attn_concat_proj + LN over (f,c) + residual (+ speaker gain); persistent, grid-stride over frames
@@ -344,7 +364,9 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
 #pragma unroll 1
         for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{});
         row_tile(NF / 16, std::true_type{});
+        QKV_STAMP(2);
         __syncthreads();
+        QKV_STAMP(3);
 
         // joint LayerNorm over all 97*64 values of the frame (flat index f*64 + c), float4 granules
         float4 v[NSLOT];

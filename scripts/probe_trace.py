@@ -55,3 +55,10 @@ if lib.raw("lh_probe_be_trace_read")(bb.ctypes.data_as(ctypes.c_void_p)) == 0:
           " gather + spectrum split", int(b[14] - b[13]), "| inside the product phase: load issue", int(b[15] - b[12]),
           "wave 0's products", int(b[16] - b[15]), "barrier wait", int(b[13] - b[16]))
     print("tile start: Sx copy + barrier", int(b[17] - b[0]), " setup", int(b[18] - b[17]), " ring priming (16 loads issued)", int(b[1] - b[18]))
+
+# QKV frame kernel: one frame of workgroup 5
+qq = np.zeros(16, dtype=np.uint64)
+if lib.raw("lh_probe_qkv_trace_read")(qq.ctypes.data_as(ctypes.c_void_p)) == 0:
+    q = qq.astype(np.int64)
+    print("QKV frame (cycles): stage + barrier", int(q[1] - q[0]), " prefetch issue + 49 products", int(q[2] - q[1]), " barrier", int(q[3] - q[2]),
+          " Q/K LayerNorm + stores", int(q[4] - q[3]), " V LayerNorm + stores", int(q[5] - q[4]), " total", int(q[5] - q[0]))
