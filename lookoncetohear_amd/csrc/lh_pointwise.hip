@@ -364,9 +364,7 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
 #pragma unroll 1
         for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{});
         row_tile(NF / 16, std::true_type{});
-        QKV_STAMP(2);
         __syncthreads();
-        QKV_STAMP(3);
 
         // joint LayerNorm over all 97*64 values of the frame (flat index f*64 + c), float4 granules
         float4 v[NSLOT];
@@ -385,21 +383,29 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
             if (tid + 256 * k < N4) vs += dx * dx + dy * dy + dz * dz + dw * dw;
         }
         const float rstd = rsqrtf(block_sum_256(vs, red) * (1.0f / N) + LN_EPS);
+        // residual + normalised value per slot, then (block 0 only) ALL speaker-gain loads of the frame, then the stores:
+        // vmcnt counts loads and stores in one order, so a gain load issued behind the previous slot's store is usable only
+        // once that store has been acknowledged — interleaved, every slot paid a store round trip
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            v[k].x = rv[k].x + (v[k].x - mean) * rstd * pw[k].x + pb[k].x;
+            v[k].y = rv[k].y + (v[k].y - mean) * rstd * pw[k].y + pb[k].y;
+            v[k].z = rv[k].z + (v[k].z - mean) * rstd * pw[k].z + pb[k].z;
+            v[k].w = rv[k].w + (v[k].w - mean) * rstd * pw[k].w + pb[k].w;
+        }
+        if (gain) {
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k)
+                rv[k] = *reinterpret_cast<const float4*>(&gain[(long)b * N + (long)min(tid + 256 * k, N4 - 1) * 4]);
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k) {
+                v[k].x *= rv[k].x; v[k].y *= rv[k].y; v[k].z *= rv[k].z; v[k].w *= rv[k].w;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) {
             const int i = tid + 256 * k;
-            if (i < N4) {
-                float4 o;
-                o.x = rv[k].x + (v[k].x - mean) * rstd * pw[k].x + pb[k].x;
-                o.y = rv[k].y + (v[k].y - mean) * rstd * pw[k].y + pb[k].y;
-                o.z = rv[k].z + (v[k].z - mean) * rstd * pw[k].z + pb[k].z;
-                o.w = rv[k].w + (v[k].w - mean) * rstd * pw[k].w + pb[k].w;
-                if (gain) {
-                    const float4 gv = *reinterpret_cast<const float4*>(&gain[(long)b * N + i * 4]);
-                    o.x *= gv.x; o.y *= gv.y; o.z *= gv.z; o.w *= gv.w;
-                }
-                *reinterpret_cast<float4*>(&out[fr + i * 4]) = o;
-            }
+            if (i < N4) *reinterpret_cast<float4*>(&out[fr + i * 4]) = v[k];
         }
     }
 }
