@@ -33,6 +33,12 @@ constexpr int AT_PKS = 3;                     // 32-key steps in P.V (96 >= 32 +
 constexpr int AT_PP = AT_PKS * 32 + 8;        // P row stride in halves (208 bytes: conflict-free ds_read_b128)
 constexpr int AT_CG = (DV + 63) / 64;         // 25 column groups of 64 V columns
 
+#if defined(LH_PROBE_TRACE)               // timing probe build only (scripts/probe_trace.py): workgroup 803, wave 0
+__device__ unsigned long long lh_attn_trace_buf[16];
+#define AT_STAMP(k) do { if (blockIdx.x == 803 && blockIdx.y == 0 && tid == 0) lh_attn_trace_buf[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AT_STAMP(k) do { } while (0)
+#endif
 template <int MQ, int RING, int TQ = 16 * MQ>
 __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restrict__ q, const _Float16* __restrict__ kx,
                                                        const _Float16* __restrict__ vx, float* __restrict__ merged,
@@ -59,6 +65,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
     const _Float16* kb = kx + ((long)bh * TKP + t0) * LDQKH;
     const _Float16* vb = vx + ((long)bh * TKP + t0) * LDVH;
 
+    AT_STAMP(0);
     // ---- scores: S[i][n] = <Q[t0+i], Kx[t0+n]>, feature k-steps s = wave, wave+4, ... of 19
     {
         f32x4 am[MQ][ND];
@@ -116,7 +123,9 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
                     if (TQ == 16 * MQ || row < TQ) sp[wave][row][d * 16 + l15] = am[mq][d][r];
                 }
     }
+    AT_STAMP(1);
     __syncthreads();
+    AT_STAMP(2);
 
     // ---- softmax over the 50 slots n = i .. i+49 of query i; 16 threads per query, P as fp16 hi/lo rows
     {
@@ -159,7 +168,9 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
             }
         }
     }
+    AT_STAMP(3);
     __syncthreads();
+    AT_STAMP(4);
 
     // ---- O = P . Vx ; each wave takes column groups of 64 (4 MFMA column tiles interleaved so a lane loads one
     //      [hi 4 | lo 4] quad of a V row per key); the head merge is fused into the store
@@ -242,6 +253,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
             }
         }
     }
+    AT_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -318,6 +330,13 @@ __global__ void __launch_bounds__(256) k_ring_unpack(const _Float16* __restrict_
     }
 }
 
+}  // namespace lh
+#if defined(LH_PROBE_TRACE)
+extern "C" int lh_probe_attn_trace_read(unsigned long long* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::lh_attn_trace_buf), sizeof(lh::lh_attn_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
+namespace lh {
 static int g_attn_mq = 0;              // lh_set_tuning key 4: 0 = automatic, 1 / 2 = query tiles of 16 frames per workgroup,
                                        // 3 = 40 frames in three tiles
 int attn_set_mq(int v) {

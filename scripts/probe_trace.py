@@ -62,3 +62,10 @@ if lib.raw("lh_probe_qkv_trace_read")(qq.ctypes.data_as(ctypes.c_void_p)) == 0:
     q = qq.astype(np.int64)
     print("QKV frame (cycles): stage + barrier", int(q[1] - q[0]), " prefetch issue + 49 products", int(q[2] - q[1]), " barrier", int(q[3] - q[2]),
           " Q/K LayerNorm + stores", int(q[4] - q[3]), " V LayerNorm + stores", int(q[5] - q[4]), " total", int(q[5] - q[0]))
+
+# attention: workgroup 803 (wave 0)
+aa = np.zeros(16, dtype=np.uint64)
+if lib.raw("lh_probe_attn_trace_read")(aa.ctypes.data_as(ctypes.c_void_p)) == 0:
+    a = aa.astype(np.int64)
+    print("attention workgroup (cycles): scores", int(a[1] - a[0]), " barrier", int(a[2] - a[1]), " softmax", int(a[3] - a[2]),
+          " barrier", int(a[4] - a[3]), " P.V + store", int(a[5] - a[4]), " total", int(a[5] - a[0]))
