@@ -180,14 +180,14 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             }
             __syncthreads();
             if (tr_it) BE_STAMP(12);
-            // Refill the two ring slots UNCONDITIONALLY (frame index clamped to the clip: a frame past the tile is loaded
-            // and never used): with the loads under `if (fr + BE_RING < fr_end)` the compiler cannot count the outstanding
+            // Refill the two ring slots UNCONDITIONALLY (frame index clamped to the tile: past its end the tile's last frame
+            // is loaded again — a cache hit — and never used): with the loads under `if (fr + BE_RING < fr_end)` the compiler cannot count the outstanding
             // loads at the loop head and waits for vmcnt(0) there, i.e. for the loads it has just issued — every pair of
             // frames then paid a full HBM round trip (s_memtime trace: 8.5 k cycles per pair against ~3 k of work).
             // (frames fr + BE_RING >= fr_first + 4 >= 2: never the carried halo frames)
             // The second slot is refilled behind the products: all eight waves issuing both frames' loads at the same point
             // queued 2000 cycles on the CU's vector-memory path.
-            load_frame_y(min(fr + BE_RING, T - 1), stg[u]);
+            load_frame_y(min(fr + BE_RING, fr_end - 1), stg[u]);
             if (tr_it) BE_STAMP(15);
 
             // P[fr + q] = Y[fr + q] (97 x 64) * Wd (64 x 48).  Wave w < 7 owns row tile w of both frames: its A fragments
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            load_frame_y(min(fr + 1 + BE_RING, T - 1), stg[u + 1]);
+            load_frame_y(min(fr + 1 + BE_RING, fr_end - 1), stg[u + 1]);
             if (tr_it) BE_STAMP(16);
             __syncthreads();
             if (tr_it) BE_STAMP(13);
