@@ -13,9 +13,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_stream.hip", "lh_comm.hip"]
+SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_recur.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_stream.hip", "lh_comm.hip"]
 LIB = os.path.join(PKG, "_lookonce_hip.so")
 ARCH = "gfx950"
+# per-file flags.  lh_recur.hip: its recurrent steps are hand-ordered (one MFMA, then the vector instructions that fit in its
+# shadow, then a scheduling fence); the SLP vectoriser would gather the scalar fp32 operations of different slots into
+# packed instructions at one place and undo that order.
+FILE_FLAGS = {"lh_recur.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(dst, srcs):
@@ -39,7 +43,7 @@ def build_hip(force: bool = False, verbose: bool = True, extra_flags=(), out: st
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *flags, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -1033,6 +1033,10 @@ static int cu_count() {
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [3] 0 = no issue-priority de-phasing
 }
 namespace lh { int attn_set_mq(int v); }      // lh_attn.hip
+namespace lh {                                // lh_recur.hip
+int launch_intra_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin, float* out,
+                    int nseq, int nstep, int sdiv, int so, int si, int ps, int dir, int accumulate, hipStream_t st);
+}
 namespace lh { int backend_set_runs(int v); } // lh_backend.hip
 #if defined(LH_PROBE_TRACE)
 extern "C" int lh_probe_trace_read(unsigned long long* host_dst) {
@@ -1121,7 +1125,10 @@ extern "C" int lh_intra_block(const float* x, const void* w_pk, const float* b_s
     // sequence = frame (b,t), step = frequency bin; forward launch then reverse launch (accumulating)
     int rc = LH_OK;
     for (int dir = 0; dir < 2 && rc == LH_OK; ++dir)
-        rc = launch_lstm_lin<1>(x, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, nullptr, nullptr,
+        if (g_tune[2] == 1)                       // software-pipelined step (lh_recur.hip)
+            rc = launch_intra_xp(x, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, out, n_frames,
+                                 NF, 1, NF, 0, 1, dir, dir, st);
+        else rc = launch_lstm_lin<1>(x, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, nullptr, nullptr,
                                 nullptr, nullptr, out, n_frames, NF, 1, NF, 0, 1, dir, dir, st);
     return rc;
 }

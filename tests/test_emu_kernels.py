@@ -91,6 +91,26 @@ def test_fused_intra_path_forced_small(emu_net, oracle_cfg_sd):
         assert (fm[k] - fo[k]).abs().max() < TOL, k
 
 
+def test_pipelined_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
+    """k_intra_xp (lh_recur.hip: x half of the gates one step ahead, hand-ordered step) selected with lh_set_tuning(2, 1)
+    at the same tiny size: 38 frames = 3 sequence tiles, last one ragged, both directions."""
+    cfg, sd = oracle_cfg_sd
+    lib = emu_net._lib_override
+    B, T = 2, 19
+    d = synth.batch([3, 4], 128 * T + 64)
+    st = O.random_state(cfg, B, 3)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    saved = emu_net.fuse_intra_min_frames
+    emu_net.fuse_intra_min_frames = 1
+    lib.call("lh_set_tuning", 2, 1)
+    try:
+        y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    finally:
+        emu_net.fuse_intra_min_frames = saved
+        lib.call("lh_set_tuning", 2, 0)
+    assert (y - yo).abs().max() < TOL
+
+
 def test_tiled_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     """The mid-size intra path (lh_ln_lstm_intra: 16-sequence MFMA tiles + lh_linear_res, used between 128 and 8192
     frames) forced at a size where `Net` would pick the streaming mat-vec kernel."""
