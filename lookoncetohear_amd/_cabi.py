@@ -97,4 +97,8 @@ def load() -> Lib:
     if _hip_lib is None:
         # LOOKONCE_HIP_LIB: another build of the same ABI (A/B timing of kernel revisions inside one gpurun call)
         _hip_lib = Lib(os.environ.get("LOOKONCE_HIP_LIB", HIP_LIB_PATH))
+        # LOOKONCE_TUNE="key=value,...": lh_set_tuning switches applied at load (A/B runs of the whole test suite)
+        for kv in filter(None, os.environ.get("LOOKONCE_TUNE", "").split(",")):
+            k, v = kv.split("=")
+            _hip_lib.call("lh_set_tuning", int(k), int(v))
     return _hip_lib

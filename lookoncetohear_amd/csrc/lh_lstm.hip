@@ -1036,6 +1036,10 @@ namespace lh { int attn_set_mq(int v); }      // lh_attn.hip
 namespace lh {                                // lh_recur.hip
 int launch_intra_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin, float* out,
                     int nseq, int nstep, int sdiv, int so, int si, int ps, int dir, int accumulate, hipStream_t st);
+int xp_set(int key, int v);
+int launch_inter_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                    const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep, int sdiv, int so,
+                    int si, int ps, hipStream_t st);
 }
 namespace lh { int backend_set_runs(int v); } // lh_backend.hip
 #if defined(LH_PROBE_TRACE)
@@ -1046,6 +1050,7 @@ extern "C" int lh_probe_trace_read(unsigned long long* host_dst) {
 extern "C" int lh_set_tuning(int key, int value) {
     if (key == 4) return lh::attn_set_mq(value);
     if (key == 6) return lh::backend_set_runs(value);
+    if (key >= 7 && key < 16) return lh::xp_set(key, value);      // lh_recur.hip switches
     if (key < 0 || key >= 8) return LH_ERR_ARG;
     lh::g_tune[key] = value;
     if (key == 3) lh::g_dephase = value;
@@ -1142,6 +1147,9 @@ extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_s
     // sequence s = b*97 + f; step = frame t; row(s, t) = (b*T + t)*97 + f.  Eight-wave tiles (k_lstm_lin8p): the pass is a
     // 625-step dependent chain, two waves per SIMD cover each other's latencies
     const int nseq = B * NF;
+    if (g_tune[5] == 1)                           // hand-ordered step (lh_recur.hip)
+        return launch_inter_xp(x, w_pk, b_sum, wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF,
+                               (hipStream_t)stream);
     hipLaunchKernelGGL(k_lstm_lin8p, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,
                            b_sum, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF, 0, 0);
     return check_launch();

@@ -32,10 +32,6 @@ constexpr int XP_AP = 144;      // fp16 elements per LDS row: [x 64 | h 64] + 16
 constexpr int XP_LSP = 68;      // fp32 projection rows: 64 + 4 pad
 constexpr float XP_K2 = -2.0f * LOG2E;
 
-// sched_group_barrier masks (LLVM AMDGPU): 0x2 VALU (not MFMA, not transcendental), 0x8 MFMA, 0x20 VMEM read,
-// 0x40 VMEM write, 0x100 DS read, 0x200 DS write, 0x400 transcendental
-#define XP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-
 // compile-time loop / zipper helpers
 template <class F, int... I>
 __device__ __forceinline__ void xp_sf(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -56,25 +52,25 @@ __device__ __forceinline__ void xp_zip(MF& mf, Ops& ops) {
     });
 }
 
-#ifndef XP_H_VALU
-#define XP_H_VALU 2            // plain vector instructions behind each phase-H MFMA
-#endif
-#ifndef XP_C_VALU
-#define XP_C_VALU 2            // plain vector instructions behind each phase-C MFMA
-#endif
-#ifndef XP_C_TRANS
-#define XP_C_TRANS 1           // transcendentals behind each phase-C MFMA
+#if defined(XP_X2)             // timing / error probe: x half as hi*hi + hi*lo_W only (activations rounded to fp16)
+constexpr int XP_XN = 8;
+#else
+constexpr int XP_XN = 12;      // MFMAs per k-step of the x half: 4 gates x (hi*hi, hi*lo, lo*hi)
 #endif
 
 __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
                                                      const float* __restrict__ blin, float* out, int nseq, int nstep,
-                                                     int sdiv, int so, int si, int ps, int dir, int accumulate) {
+                                                     int sdiv, int so, int si, int ps, int dir, int accumulate, int prio) {
     constexpr int NS = 16;
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * XP_AP];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * XP_AP];
     __shared__ __attribute__((aligned(16))) float ls[2 * NS * XP_LSP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (prio) {       // A/B switch: static issue priority for one of the two workgroups that share a CU
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID[3:0] = wave slot
+        if (hw_id & 1) __builtin_amdgcn_s_setprio(2);
+    }
     const int s0 = blockIdx.x * NS;
     const int g4 = lane >> 4, l15 = lane & 15;
     const int q = tid & 15;
@@ -244,7 +240,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
                 constexpr int ks = i / 3, p = i % 3;
                 am = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? hl[ks] : hh[ks], p == 1 ? lwl[ks] : lwh[ks], am, 0, 0, 0);
             } else {
-                constexpr int j = i - 6, ks = j / 12, p = (j % 12) / 4, g = j % 4;
+                constexpr int j = i - 6, ks = j / XP_XN, p = (j % XP_XN) / 4, g = j % 4;
                 const f32x4 c0 = j < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : gx[g];
                 gx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? xl[ks] : xh[ks], p == 1 ? wl[g][ks] : wh[g][ks], c0, 0, 0, 0);
             }
@@ -299,7 +295,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
             [&] { cA(R2{}); }, [&] { cA(R3{}); }, [&] { cB(R2{}); }, [&] { cB(R3{}); }, [&] { cC(R2{}); }, [&] { cC(R3{}); },
             [&] { cD(R2{}); }, [&] { cD(R3{}); }, [&] { cE(R2{}); }, [&] { cE(R3{}); }, [&] { cF(R2{}); }, [&] { cF(R3{}); },
             [&] { cG(R2{}); }, [&] { cG(R3{}); }, [&] { cH(R2{}); }, [&] { cH(R3{}); }, [&] { cI(R2{}); }, [&] { cI(R3{}); });
-        xp_zip<30>(c_mfma, c_ops);
+        xp_zip<6 + 2 * XP_XN>(c_mfma, c_ops);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -345,10 +341,359 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_inter_xp: the inter pass (LayerNorm + causal LSTM over time with carried (h0, c0) + Linear + residual,
+// tfgridnet_causal.py:521-538) with the same hand-ordered step.  Tile, LDS images, weight images and roles are those of
+// k_lstm_lin8p (lh_lstm.hip): 16 sequences x all steps per 8-wave workgroup, one per CU; transposed gate GEMM (weights =
+// MFMA A operand, rows ordered (unit, gate)) so a lane holds the four gates of two cells; waves 0..3 ("LIN") also run the
+// output projection and finish / fetch the output rows, waves 4..7 normalise and split x; the x half of step t+1 is
+// computed during step t.  Per step and wave:
+//   phase H:  12 MFMAs (h half, on the chain)                          ||  the wave's row-wise role
+//   phase C:  12 MFMAs (x half of step t+1) [+ 6 projection, LIN]      ||  the two cell updates (20 transcendentals)
+// ------------------------------------------------------------------------------------------------------
+template <bool LIN>
+struct xp_tag { static constexpr bool value = LIN; };
+
+__global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
+                                                     const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
+                                                     const float* __restrict__ blin, const float* __restrict__ h0,
+                                                     const float* __restrict__ c0, float* __restrict__ hN,
+                                                     float* __restrict__ cN, float* out, int nseq, int nstep, int sdiv,
+                                                     int so, int si, int ps, int dir, int accumulate) {
+    constexpr int NS = 16;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * XP_AP];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * XP_AP];
+    __shared__ __attribute__((aligned(16))) float ls[2 * NS * XP_LSP];
+    __shared__ __attribute__((aligned(16))) float hf[NS * XP_LSP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s0 = blockIdx.x * NS;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const bool lin_wave = wave < 4;
+    const int q = tid & 15, rrow = (tid & 255) >> 4;
+    const int unit0 = 8 * wave + g4;
+
+    auto row_of0 = [&](int s) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si; };
+    const long wg_row0 = row_of0(min(s0, nseq - 1));
+    const unsigned voff = (unsigned)((row_of0(min(s0 + rrow, nseq - 1)) - wg_row0) * (C * 4) + q * 16);
+    const char* xb = reinterpret_cast<const char*>(x) + wg_row0 * (C * 4);
+    char* ob = reinterpret_cast<char*>(out) + wg_row0 * (C * 4);
+    const char* bsrc = reinterpret_cast<const char*>(
+        accumulate ? reinterpret_cast<unsigned long long>(ob) : reinterpret_cast<unsigned long long>(xb));
+    const long step_bytes = (long)ps * (C * 4);
+    auto step_pos = [&](int it) -> int { it = min(max(it, 0), nstep - 1); return dir ? (nstep - 1 - it) : it; };
+
+    xp_f16x8 wh[2][4], wl[2][4];          // image [dir][wave][tile m][ks][lane][hi 8 | lo 8] (weights.py pack_lstm_f16x3_w8)
+    {
+        const _Float16* wp = w_pk + ((long)(dir * 8 + wave) * 8 * 64 + lane) * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wh[m][ks] = *reinterpret_cast<const xp_f16x8*>(wp + (long)(m * 4 + ks) * 64 * 16);
+                wl[m][ks] = *reinterpret_cast<const xp_f16x8*>(wp + (long)(m * 4 + ks) * 64 * 16 + 8);
+            }
+    }
+    xp_f16x8 lwh[2], lwl[2];
+    float lbias = 0.0f;
+    if (lin_wave) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            lwh[ks] = *reinterpret_cast<const xp_f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16]);
+            lwl[ks] = *reinterpret_cast<const xp_f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16 + 8]);
+        }
+        if (!accumulate) lbias = blin[wave * 16 + l15];
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) lwh[ks] = lwl[ks] = xp_f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float eb[2][4];                       // 2^bias: the gate bias enters the cell update as a factor (see k_intra_xp)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) eb[m][g] = __builtin_amdgcn_exp2f(b_sum[dir * 256 + g * 64 + unit0 + 4 * m]);
+
+    const int a_frag = l15 * XP_AP + g4 * 8;
+    const int a_cell = l15 * XP_AP + C + unit0;
+    const int a_row = rrow * XP_AP + q * 4;
+    const int l_row = rrow * XP_LSP + q * 4;
+    const int l_lin = (g4 * 4) * XP_LSP + wave * 16 + l15;
+
+    auto store_split4 = [&](int idx, float a, float b, float c, float d) {
+        xp_f16x4 h4, l4;
+        const float v[4] = {a, b, c, d};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const _Float16 th = (_Float16)v[i];
+            h4[i] = th;
+            l4[i] = (_Float16)(v[i] - (float)th);
+        }
+        *reinterpret_cast<xp_f16x4*>(&ahi[idx]) = h4;
+        *reinterpret_cast<xp_f16x4*>(&alo[idx]) = l4;
+    };
+    auto norm_store_x = [&](int buf, float4 v) {
+        const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
+        const float rstd = __builtin_amdgcn_rsqf(var + LN_EPS);
+        store_split4(buf * NS * XP_AP + a_row, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
+    };
+    auto load_row = [&](const char* base, int it) -> float4 {
+        return *reinterpret_cast<const float4*>(base + step_pos(it) * step_bytes + voff);
+    };
+    auto x_half = [&](int buf, f32x4 (&g)[2]) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) g[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const xp_f16x8 xh = *reinterpret_cast<const xp_f16x8*>(&ahi[buf * NS * XP_AP + a_frag + ks * 32]);
+            const xp_f16x8 xl = *reinterpret_cast<const xp_f16x8*>(&alo[buf * NS * XP_AP + a_frag + ks * 32]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) g[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][ks], xh, g[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) g[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[m][ks], xl, g[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) g[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[m][ks], xh, g[m], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: x_0, x_1 normalised into the two buffers, x_2 in flight; h_{-1}; x half of step 0
+    float creg[2], hreg[2];               // creg: cell state scaled by -2 log2 e
+    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!lin_wave) {
+        norm_store_x(0, load_row(xb, 0));
+        norm_store_x(1, load_row(xb, 1));
+        carry = load_row(xb, 2);
+    } else {
+        const int s = min(s0 + rrow, nseq - 1);
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h0) hv = *reinterpret_cast<const float4*>(&h0[(long)s * H + q * 4]);
+        store_split4(a_row + C, hv.x, hv.y, hv.z, hv.w);
+    }
+    {
+        const int s = min(s0 + l15, nseq - 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            creg[m] = c0 ? XP_K2 * c0[(long)s * H + unit0 + 4 * m] : 0.0f;
+            hreg[m] = 0.0f;
+        }
+    }
+    __syncthreads();
+    f32x4 gx[2];
+    x_half(0, gx);
+    __syncthreads();                                  // buffer 0's x half is rewritten (x_2) in step 0
+
+    auto step = [&](int it, auto cur_tag, auto lin_tag, auto store_tag) __attribute__((always_inline)) {
+        constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+        constexpr bool LIN = decltype(lin_tag)::value;
+        constexpr bool STORE = decltype(store_tag)::value;
+        // ================= phase H: acc = (x half of this step, computed a step ago) + h_{it-1} W_hh^T  ||  row-wise role
+        xp_f16x8 bh[2], bl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bh[ks] = *reinterpret_cast<const xp_f16x8*>(&ahi[cur * NS * XP_AP + a_frag + (2 + ks) * 32]);
+            bl[ks] = *reinterpret_cast<const xp_f16x8*>(&alo[cur * NS * XP_AP + a_frag + (2 + ks) * 32]);
+        }
+        f32x4 acc[2] = {gx[0], gx[1]};
+        xp_f16x8 xh[2], xl[2];            // x fragments of step it+1 (buffer nxt): fetched ahead of phase C's first MFMA
+        auto h_mfma = [&](auto idx) __attribute__((always_inline)) {
+            constexpr int i = decltype(idx)::value, ks = i / 6, p = (i % 6) / 2, m = i % 2;
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? wl[m][2 + ks] : wh[m][2 + ks], p == 1 ? bl[ks] : bh[ks],
+                                                            acc[m], 0, 0, 0);
+        };
+        if constexpr (LIN) {
+            // rows of step it-2: base (fetched a step ago) + projection parked in ls[nxt]; then this step's base fetch
+            float4 pv, done;
+            auto h_ops = std::make_tuple(
+                [&] { pv = *reinterpret_cast<const float4*>(&ls[nxt * NS * XP_LSP + l_row]); },
+                [&] {}, [&] {}, [&] {},
+                [&] { done.x = carry.x + pv.x; done.y = carry.y + pv.y; },
+                [&] { done.z = carry.z + pv.z; done.w = carry.w + pv.w; },
+                [&] { if (STORE) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done; },
+                [&] { carry = load_row(bsrc, it - 1); });
+            xp_zip<12>(h_mfma, h_ops);
+        } else {
+            // x_{it+2} (fetched a step ago) normalised into the x half of buffer `cur`; x_{it+3} fetched
+            float4 v, y;
+            float s, t, qa, qb, rstd;
+            xp_f16x4 h4, l4;
+            auto h_ops = std::make_tuple(
+                [&] { v = carry; s = v.x + v.y; t = v.z + v.w; },
+                [&] { s += t; },
+                [&] { s = row_ror_add<8>(s); },
+                [&] { s = row_ror_add<4>(s); },
+                [&] { s = row_ror_add<2>(s); },
+                [&] { s = row_ror_add<1>(s); },
+                [&] { v.x = __builtin_fmaf(s, -1.0f / C, v.x); v.y = __builtin_fmaf(s, -1.0f / C, v.y); },
+                [&] { v.z = __builtin_fmaf(s, -1.0f / C, v.z); v.w = __builtin_fmaf(s, -1.0f / C, v.w); },
+                [&] { qa = v.x * v.x; qb = v.z * v.z; },
+                [&] { qa = __builtin_fmaf(v.y, v.y, qa); qb = __builtin_fmaf(v.w, v.w, qb); },
+                [&] { qa += qb; },
+                [&] { qa = row_ror_add<8>(qa); },
+                [&] { qa = row_ror_add<4>(qa); },
+                [&] { qa = row_ror_add<2>(qa); },
+                [&] { qa = row_ror_add<1>(qa); },
+                [&] { rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qa, 1.0f / C, LN_EPS)); },
+                [&] { carry = load_row(xb, it + 3); },
+                [&] { y.x = v.x * rstd; y.y = v.y * rstd; },
+                [&] { y.z = v.z * rstd; y.w = v.w * rstd; },
+                [&] { h4[0] = (_Float16)y.x; h4[1] = (_Float16)y.y; h4[2] = (_Float16)y.z; h4[3] = (_Float16)y.w; },
+                [&] { l4[0] = (_Float16)(y.x - (float)h4[0]); l4[1] = (_Float16)(y.y - (float)h4[1]); },
+                [&] { l4[2] = (_Float16)(y.z - (float)h4[2]); l4[3] = (_Float16)(y.w - (float)h4[3]); },
+                [&] {
+                    *reinterpret_cast<xp_f16x4*>(&ahi[cur * NS * XP_AP + a_row]) = h4;
+                    *reinterpret_cast<xp_f16x4*>(&alo[cur * NS * XP_AP + a_row]) = l4;
+                },
+                [&] {
+                    xh[0] = *reinterpret_cast<const xp_f16x8*>(&ahi[nxt * NS * XP_AP + a_frag]);
+                    xl[0] = *reinterpret_cast<const xp_f16x8*>(&alo[nxt * NS * XP_AP + a_frag]);
+                    xh[1] = *reinterpret_cast<const xp_f16x8*>(&ahi[nxt * NS * XP_AP + a_frag + 32]);
+                    xl[1] = *reinterpret_cast<const xp_f16x8*>(&alo[nxt * NS * XP_AP + a_frag + 32]);
+                });
+            xp_zip<12>(h_mfma, h_ops);
+        }
+        // ================= phase C: [projection of h_{it-1},] x half of step it+1  ||  the two cell updates of step it
+        f32x4 am = f32x4{lbias, lbias, lbias, lbias};
+        constexpr int NL = LIN ? 6 : 0;
+        auto c_mfma = [&](auto idx) __attribute__((always_inline)) {
+            constexpr int i = decltype(idx)::value;
+            if constexpr (i < NL) {
+                constexpr int ks = i / 3, p = i % 3;
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? bl[ks] : bh[ks], p == 1 ? lwl[ks] : lwh[ks], am, 0, 0, 0);
+            } else {
+                constexpr int j = i - NL, ks = j / 6, p = (j % 6) / 2, m = j % 2;
+                const f32x4 c0v = j < 2 ? f32x4{0.f, 0.f, 0.f, 0.f} : gx[m];
+                gx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? wl[m][ks] : wh[m][ks], p == 1 ? xl[ks] : xh[ks], c0v, 0, 0, 0);
+            }
+        };
+        float tc[2];
+        auto cA = [&](auto m_) { constexpr int m = decltype(m_)::value; acc[m][0] = __builtin_amdgcn_exp2f(acc[m][0]); acc[m][1] = __builtin_amdgcn_exp2f(acc[m][1]); };
+        auto cB = [&](auto m_) { constexpr int m = decltype(m_)::value; acc[m][2] = __builtin_amdgcn_exp2f(acc[m][2]); acc[m][3] = __builtin_amdgcn_exp2f(acc[m][3]); };
+        auto cC = [&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[m][g] = __builtin_fmaf(acc[m][g], eb[m][g], 1.0f);
+        };
+        auto cD = [&](auto m_) { constexpr int m = decltype(m_)::value; acc[m][0] = __builtin_amdgcn_rcpf(acc[m][0]); acc[m][1] = __builtin_amdgcn_rcpf(acc[m][1]); };
+        auto cE = [&](auto m_) { constexpr int m = decltype(m_)::value; acc[m][2] = __builtin_amdgcn_rcpf(acc[m][2]); acc[m][3] = __builtin_amdgcn_rcpf(acc[m][3]); };
+        auto cF = [&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            const float g2 = __builtin_fmaf(2.0f * XP_K2, acc[m][2], -XP_K2);
+            creg[m] = __builtin_fmaf(acc[m][1], creg[m], acc[m][0] * g2);
+        };
+        auto cG = [&](auto m_) { constexpr int m = decltype(m_)::value; tc[m] = 1.0f + __builtin_amdgcn_exp2f(creg[m]); };
+        auto cH = [&](auto m_) { constexpr int m = decltype(m_)::value; tc[m] = __builtin_amdgcn_rcpf(tc[m]); };
+        auto cI = [&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            hreg[m] = acc[m][3] * __builtin_fmaf(2.0f, tc[m], -1.0f);
+            const _Float16 th = (_Float16)hreg[m];
+            const _Float16 tl = (_Float16)(hreg[m] - (float)th);
+            ahi[nxt * NS * XP_AP + a_cell + 4 * m] = th;
+            alo[nxt * NS * XP_AP + a_cell + 4 * m] = tl;
+        };
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        auto c_ops = std::make_tuple(
+            [&] {
+                if constexpr (LIN) {          // (the LN waves fetched them at the end of phase H: their first MFMA here needs them)
+                    xh[0] = *reinterpret_cast<const xp_f16x8*>(&ahi[nxt * NS * XP_AP + a_frag]);
+                    xl[0] = *reinterpret_cast<const xp_f16x8*>(&alo[nxt * NS * XP_AP + a_frag]);
+                }
+            },
+            [&] {
+                if constexpr (LIN) {
+                    xh[1] = *reinterpret_cast<const xp_f16x8*>(&ahi[nxt * NS * XP_AP + a_frag + 32]);
+                    xl[1] = *reinterpret_cast<const xp_f16x8*>(&alo[nxt * NS * XP_AP + a_frag + 32]);
+                }
+            },
+            [&] { cA(M0{}); }, [&] { cA(M1{}); }, [&] { cB(M0{}); }, [&] { cB(M1{}); }, [&] { cC(M0{}); }, [&] { cC(M1{}); },
+            [&] { cD(M0{}); }, [&] { cD(M1{}); }, [&] { cE(M0{}); }, [&] { cE(M1{}); },
+            [&] {
+                if constexpr (LIN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ls[cur * NS * XP_LSP + r * XP_LSP + l_lin] = am[r];
+                }
+            },
+            [&] { cF(M0{}); }, [&] { cF(M1{}); }, [&] { cG(M0{}); }, [&] { cG(M1{}); }, [&] { cH(M0{}); }, [&] { cH(M1{}); },
+            [&] { cI(M0{}); }, [&] { cI(M1{}); });
+        xp_zip<12 + NL>(c_mfma, c_ops);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto run = [&](auto lin_tag) __attribute__((always_inline)) {
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        step(0, B0{}, lin_tag, std::false_type{});
+        if (nstep > 1) step(1, B1{}, lin_tag, std::false_type{});
+        int it = 2;
+        for (; it + 1 < nstep; it += 2) {
+            step(it, B0{}, lin_tag, std::true_type{});
+            step(it + 1, B1{}, lin_tag, std::true_type{});
+        }
+        if (it < nstep) step(it, B0{}, lin_tag, std::true_type{});
+    };
+    if (lin_wave) run(std::true_type{});
+    else run(std::false_type{});
+
+    // ---- drain: rows of the last two steps (projection of h_{nstep-1} still to do), final state
+    const int lastb = nstep & 1;
+    if (lin_wave) {
+        if (nstep >= 2) {
+            const float4 pv = *reinterpret_cast<const float4*>(&ls[(lastb ^ 1) * NS * XP_LSP + l_row]);
+            *reinterpret_cast<float4*>(ob + step_pos(nstep - 2) * step_bytes + voff) =
+                make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+        }
+        carry = load_row(bsrc, nstep - 1);
+        f32x4 am = f32x4{lbias, lbias, lbias, lbias};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const xp_f16x8 ah = *reinterpret_cast<const xp_f16x8*>(&ahi[lastb * NS * XP_AP + a_frag + (2 + ks) * 32]);
+            const xp_f16x8 al = *reinterpret_cast<const xp_f16x8*>(&alo[lastb * NS * XP_AP + a_frag + (2 + ks) * 32]);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwh[ks], am, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, lwl[ks], am, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, lwh[ks], am, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ls[lastb * NS * XP_LSP + r * XP_LSP + l_lin] = am[r];
+    }
+    if (hN) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) hf[l15 * XP_LSP + unit0 + 4 * m] = hreg[m];
+    }
+    __syncthreads();
+    if (lin_wave) {
+        const float4 pv = *reinterpret_cast<const float4*>(&ls[lastb * NS * XP_LSP + l_row]);
+        *reinterpret_cast<float4*>(ob + step_pos(nstep - 1) * step_bytes + voff) =
+            make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
+    } else if (hN && s0 + rrow < nseq) {
+        *reinterpret_cast<float4*>(&hN[(long)(s0 + rrow) * H + q * 4]) = *reinterpret_cast<const float4*>(&hf[l_row]);
+    }
+    if (cN && s0 + l15 < nseq) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + 4 * m] = creg[m] * (1.0f / XP_K2);
+    }
+}
+
+int launch_inter_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                    const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep, int sdiv, int so,
+                    int si, int ps, hipStream_t st) {
+    hipLaunchKernelGGL(k_inter_xp, dim3((nseq + 15) / 16), dim3(512), 0, st, x, (const _Float16*)w_pk, b_sum,
+                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, 0, 0);
+    return check_launch();
+}
+
+static int g_xp_lds_pad = 0;      // lh_set_tuning(7, bytes): dynamic LDS added to k_intra_xp launches (timing probe: 1 workgroup per CU)
+static int g_xp_prio = 0;         // lh_set_tuning(8, v): 1 = the wave in the odd hardware slot of a SIMD runs at issue priority 2
+int xp_set(int key, int v) {
+    if (key == 7) g_xp_lds_pad = v < 0 ? 0 : v;
+    if (key == 8) g_xp_prio = v;
+    return LH_OK;
+}
+
 int launch_intra_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin, float* out,
                     int nseq, int nstep, int sdiv, int so, int si, int ps, int dir, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(k_intra_xp, dim3((nseq + 15) / 16), dim3(256), 0, st, x, (const _Float16*)w_pk, b_sum,
-                       (const _Float16*)wlin_pk, blin, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate);
+    hipLaunchKernelGGL(k_intra_xp, dim3((nseq + 15) / 16), dim3(256), g_xp_lds_pad, st, x, (const _Float16*)w_pk, b_sum,
+                       (const _Float16*)wlin_pk, blin, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate, g_xp_prio);
     return check_launch();
 }
 

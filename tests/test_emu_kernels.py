@@ -111,6 +111,26 @@ def test_pipelined_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     assert (y - yo).abs().max() < TOL
 
 
+def test_pipelined_inter_kernel(emu_net, oracle_cfg_sd):
+    """k_inter_xp (lh_recur.hip) selected with lh_set_tuning(5, 1): B=6 (582 sequences = 37 tiles, last one ragged; above
+    the per-sequence mat-vec kernel's batch limit), T=7, carried (h0, c0) in and (hN, cN) out against the oracle."""
+    cfg, sd = oracle_cfg_sd
+    lib = emu_net._lib_override
+    B, T = 6, 7
+    d = synth.batch(list(range(20, 20 + B)), 128 * T + 64)
+    st = O.random_state(cfg, B, 13)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    lib.call("lh_set_tuning", 5, 1)
+    try:
+        y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    finally:
+        lib.call("lh_set_tuning", 5, 0)
+    assert (y - yo).abs().max() < TOL
+    fo, fm = O.flat_state(so), O.flat_state(s2)
+    for k in fo:
+        assert fm[k].shape == fo[k].shape and (fm[k] - fo[k]).abs().max() < TOL, k
+
+
 def test_tiled_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     """The mid-size intra path (lh_ln_lstm_intra: 16-sequence MFMA tiles + lh_linear_res, used between 128 and 8192
     frames) forced at a size where `Net` would pick the streaming mat-vec kernel."""
