@@ -58,6 +58,13 @@ constexpr int XP_XN = 8;
 constexpr int XP_XN = 12;      // MFMAs per k-step of the x half: 4 gates x (hi*hi, hi*lo, lo*hi)
 #endif
 
+#if defined(XP_TRACE)          // timing probe build only: s_memtime stamps of one wave of two workgroups of k_intra_xp
+__device__ unsigned long long xp_trace_buf[2 * 128 * 4];
+#define XP_STAMP(k) do { if (tr_on) tr[(it & 127) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XP_STAMP(k) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ b_sum, const _Float16* __restrict__ wlin_pk,
                                                      const float* __restrict__ blin, float* out, int nseq, int nstep,
@@ -67,6 +74,11 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * XP_AP];
     __shared__ __attribute__((aligned(16))) float ls[2 * NS * XP_LSP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(XP_TRACE)
+    __shared__ unsigned long long tr[128 * 4];
+    const int tr_slot = blockIdx.x == 7 ? 0 : (blockIdx.x == gridDim.x / 2 + 3 ? 1 : -1);
+    const bool tr_on = tr_slot >= 0 && threadIdx.x == 0 && dir == 0;
+#endif
     if (prio) {       // A/B switch: static issue priority for one of the two workgroups that share a CU
         const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID[3:0] = wave slot
         if (hw_id & 1) __builtin_amdgcn_s_setprio(2);
@@ -182,6 +194,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
         constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
         constexpr bool STORE = decltype(store_tag)::value;
         // ================= phase H: recurrent half on top of gx  ||  row-wise work
+        XP_STAMP(0);
         xp_f16x8 hh[2], hl[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -231,6 +244,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
             },
             [&] { xr = load_x(it + 3); });
         xp_zip<24>(h_mfma, h_ops);
+        XP_STAMP(1);
         // ================= phase C: projection of h_{it-1} (6 MFMAs), x half of step it+1 (24)  ||  cell update of step it
         xp_f16x8 xh[2], xl[2];
         f32x4 am = f32x4{lbias, lbias, lbias, lbias};
@@ -296,6 +310,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
             [&] { cD(R2{}); }, [&] { cD(R3{}); }, [&] { cE(R2{}); }, [&] { cE(R3{}); }, [&] { cF(R2{}); }, [&] { cF(R3{}); },
             [&] { cG(R2{}); }, [&] { cG(R3{}); }, [&] { cH(R2{}); }, [&] { cH(R3{}); }, [&] { cI(R2{}); }, [&] { cI(R3{}); });
         xp_zip<6 + 2 * XP_XN>(c_mfma, c_ops);
+        XP_STAMP(2);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -312,6 +327,10 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
         if (it < nstep) step(it, B0{}, std::true_type{});
     }
 
+#if defined(XP_TRACE)
+    if (tr_slot >= 0 && dir == 0 && threadIdx.x < 64)
+        for (int i = threadIdx.x; i < 128 * 4; i += 64) xp_trace_buf[tr_slot * 512 + i] = tr[i];
+#endif
     // ---- drain: rows of the last two steps (projection of h_{nstep-1} still to do)
     const int lastb = nstep & 1;
     if (nstep >= 2) {
@@ -698,3 +717,9 @@ int launch_intra_xp(const float* x, const void* w_pk, const float* b_sum, const 
 }
 
 }  // namespace lh
+
+#if defined(XP_TRACE)
+extern "C" int lh_probe_xp_trace_read(unsigned long long* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::xp_trace_buf), sizeof(lh::xp_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
