@@ -60,9 +60,32 @@ constexpr int XP_XN = 12;      // MFMAs per k-step of the x half: 4 gates x (hi*
 
 #if defined(XP_TRACE)          // timing probe build only: s_memtime stamps of one wave of two workgroups of k_intra_xp
 __device__ unsigned long long xp_trace_buf[2 * 128 * 4];
+__device__ unsigned long long xp_wg_log[4096 * 4];       // per workgroup: start tick, end tick, HW_ID, XCC_ID
 #define XP_STAMP(k) do { if (tr_on) tr[(it & 127) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define XP_STAMP(k) do { } while (0)
+#endif
+
+// Energy-attribution probes (timing builds only, WRONG results on purpose; scripts/power_probe.py): every kernel of the
+// path runs at the 1400 W package cap, so time is proportional to energy and removing one instruction class shows its share.
+__device__ __forceinline__ float xp_exp2(float v) {
+#if defined(XP_PROBE_NOTRANS)
+    return __builtin_fmaf(v, 0.25f, 0.5f);
+#else
+    return __builtin_amdgcn_exp2f(v);
+#endif
+}
+__device__ __forceinline__ float xp_rcp(float v) {
+#if defined(XP_PROBE_NOTRANS)
+    return __builtin_fmaf(v, -0.25f, 1.0f);
+#else
+    return __builtin_amdgcn_rcpf(v);
+#endif
+}
+#if defined(XP_PROBE_HIHI)
+constexpr int XP_NP = 1;       // probe: hi*hi products only (18 of 54 MFMAs)
+#else
+constexpr int XP_NP = 3;
 #endif
 
 __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x, const _Float16* __restrict__ w_pk,
@@ -78,6 +101,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
     __shared__ unsigned long long tr[128 * 4];
     const int tr_slot = blockIdx.x == 7 ? 0 : (blockIdx.x == gridDim.x / 2 + 3 ? 1 : -1);
     const bool tr_on = tr_slot >= 0 && threadIdx.x == 0 && dir == 0;
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memtime();
 #endif
     if (prio) {       // A/B switch: static issue priority for one of the two workgroups that share a CU
         const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID[3:0] = wave slot
@@ -204,6 +228,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
         f32x4 acc[4] = {gx[0], gx[1], gx[2], gx[3]};
         auto h_mfma = [&](auto idx) __attribute__((always_inline)) {
             constexpr int i = decltype(idx)::value, ks = i / 12, p = (i % 12) / 4, g = i % 4;
+            if constexpr (p < XP_NP)
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? hl[ks] : hh[ks], p == 1 ? wl[g][2 + ks] : wh[g][2 + ks],
                                                             acc[g], 0, 0, 0);
         };
@@ -230,9 +255,17 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
             [&] { qa = row_ror_add<1>(qa); },
             [&] {
                 rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qa, 1.0f / C, LN_EPS));   // var + eps >= 1e-5: no denormal guard
+#if defined(XP_PROBE_NOGLOBAL)
+                if (STORE && done.x == 1.2345e30f) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done;
+#else
                 if (STORE) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done;
+#endif
             },
+#if defined(XP_PROBE_NOGLOBAL)
+            [&] { if (!STORE) rr = load_base(it - 1); },
+#else
             [&] { rr = load_base(it - 1); },
+#endif
             [&] { y.x = v.x * rstd; y.y = v.y * rstd; },
             [&] { y.z = v.z * rstd; y.w = v.w * rstd; },
             [&] { h4[0] = (_Float16)y.x; h4[1] = (_Float16)y.y; h4[2] = (_Float16)y.z; h4[3] = (_Float16)y.w; },
@@ -242,7 +275,11 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
                 *reinterpret_cast<xp_f16x4*>(&ahi[cur * NS * XP_AP + a_row]) = h4;
                 *reinterpret_cast<xp_f16x4*>(&alo[cur * NS * XP_AP + a_row]) = l4;
             },
+#if defined(XP_PROBE_NOGLOBAL)
+            [&] { if (!STORE) xr = load_x(it + 3); });
+#else
             [&] { xr = load_x(it + 3); });
+#endif
         xp_zip<24>(h_mfma, h_ops);
         XP_STAMP(1);
         // ================= phase C: projection of h_{it-1} (6 MFMAs), x half of step it+1 (24)  ||  cell update of step it
@@ -252,31 +289,33 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
             constexpr int i = decltype(idx)::value;
             if constexpr (i < 6) {
                 constexpr int ks = i / 3, p = i % 3;
+                if constexpr (p < XP_NP)
                 am = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? hl[ks] : hh[ks], p == 1 ? lwl[ks] : lwh[ks], am, 0, 0, 0);
             } else {
                 constexpr int j = i - 6, ks = j / XP_XN, p = (j % XP_XN) / 4, g = j % 4;
                 const f32x4 c0 = j < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : gx[g];
+                if constexpr (p < XP_NP)
                 gx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? xl[ks] : xh[ks], p == 1 ? wl[g][ks] : wh[g][ks], c0, 0, 0, 0);
             }
         };
         float tc[4];
         // cell r of this lane, in place in the accumulators: acc[g][r] -> 2^a -> 1 + 2^(a+b) -> gate value
-        auto cA = [&](auto r_) { constexpr int r = decltype(r_)::value; acc[0][r] = __builtin_amdgcn_exp2f(acc[0][r]); acc[1][r] = __builtin_amdgcn_exp2f(acc[1][r]); };
-        auto cB = [&](auto r_) { constexpr int r = decltype(r_)::value; acc[2][r] = __builtin_amdgcn_exp2f(acc[2][r]); acc[3][r] = __builtin_amdgcn_exp2f(acc[3][r]); };
+        auto cA = [&](auto r_) { constexpr int r = decltype(r_)::value; acc[0][r] = xp_exp2(acc[0][r]); acc[1][r] = xp_exp2(acc[1][r]); };
+        auto cB = [&](auto r_) { constexpr int r = decltype(r_)::value; acc[2][r] = xp_exp2(acc[2][r]); acc[3][r] = xp_exp2(acc[3][r]); };
         auto cC = [&](auto r_) {
             constexpr int r = decltype(r_)::value;
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g][r] = __builtin_fmaf(acc[g][r], eb[g], 1.0f);
         };
-        auto cD = [&](auto r_) { constexpr int r = decltype(r_)::value; acc[0][r] = __builtin_amdgcn_rcpf(acc[0][r]); acc[1][r] = __builtin_amdgcn_rcpf(acc[1][r]); };
-        auto cE = [&](auto r_) { constexpr int r = decltype(r_)::value; acc[2][r] = __builtin_amdgcn_rcpf(acc[2][r]); acc[3][r] = __builtin_amdgcn_rcpf(acc[3][r]); };
+        auto cD = [&](auto r_) { constexpr int r = decltype(r_)::value; acc[0][r] = xp_rcp(acc[0][r]); acc[1][r] = xp_rcp(acc[1][r]); };
+        auto cE = [&](auto r_) { constexpr int r = decltype(r_)::value; acc[2][r] = xp_rcp(acc[2][r]); acc[3][r] = xp_rcp(acc[3][r]); };
         auto cF = [&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const float g2 = __builtin_fmaf(2.0f * XP_K2, acc[2][r], -XP_K2);          // -2 log2e * tanh(g)
             creg[r] = __builtin_fmaf(acc[1][r], creg[r], acc[0][r] * g2);              // scaled cell state
         };
-        auto cG = [&](auto r_) { constexpr int r = decltype(r_)::value; tc[r] = 1.0f + __builtin_amdgcn_exp2f(creg[r]); };
-        auto cH = [&](auto r_) { constexpr int r = decltype(r_)::value; tc[r] = __builtin_amdgcn_rcpf(tc[r]); };
+        auto cG = [&](auto r_) { constexpr int r = decltype(r_)::value; tc[r] = 1.0f + xp_exp2(creg[r]); };
+        auto cH = [&](auto r_) { constexpr int r = decltype(r_)::value; tc[r] = xp_rcp(tc[r]); };
         auto cI = [&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const float hv = acc[3][r] * __builtin_fmaf(2.0f, tc[r], -1.0f);
@@ -330,6 +369,12 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
 #if defined(XP_TRACE)
     if (tr_slot >= 0 && dir == 0 && threadIdx.x < 64)
         for (int i = threadIdx.x; i < 128 * 4; i += 64) xp_trace_buf[tr_slot * 512 + i] = tr[i];
+    if (threadIdx.x == 0 && dir == 0 && blockIdx.x < 4096) {
+        xp_wg_log[blockIdx.x * 4 + 0] = wg_t0;
+        xp_wg_log[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+        xp_wg_log[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+        xp_wg_log[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20);
+    }
 #endif
     // ---- drain: rows of the last two steps (projection of h_{nstep-1} still to do)
     const int lastb = nstep & 1;
@@ -721,5 +766,8 @@ int launch_intra_xp(const float* x, const void* w_pk, const float* b_sum, const 
 #if defined(XP_TRACE)
 extern "C" int lh_probe_xp_trace_read(unsigned long long* host_dst) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::xp_trace_buf), sizeof(lh::xp_trace_buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int lh_probe_xp_wglog_read(unsigned long long* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::xp_wg_log), sizeof(lh::xp_wg_log)) == hipSuccess ? 0 : 1;
 }
 #endif

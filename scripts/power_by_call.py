@@ -1,0 +1,112 @@
+"""GPU probe (test tooling): energy per C-ABI call of the B=32 forward.  Records the argument lists of one `Net.forward`,
+then replays each distinct call (its block-0 instance) in a loop for a few seconds while a second thread samples rocm-smi;
+prints ms per call, average package power, sclk and joules per call, and the same for the whole forward.
+    python scripts/power_by_call.py [key=value,...]"""
+import os
+import re
+import subprocess
+import sys
+import threading
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lookoncetohear_amd import _cabi, config, synth  # noqa: E402
+from lookoncetohear_amd.net import Net  # noqa: E402
+
+dev = torch.device("cuda:0")
+lib = _cabi.load()
+for kv in filter(None, (sys.argv[1] if len(sys.argv) > 1 else "").split(",")):
+    k, v = kv.split("=")
+    lib.call("lh_set_tuning", int(k), int(v))
+net = Net(**config.TSH_PARAMS).eval()
+net.load_state_dict(config.separator_weights(0), strict=True)
+net = net.to(dev)
+B = int(os.environ.get("PROBE_B", "32"))
+d = synth.batch(list(range(B)), 80000)
+x, e = d["mixture"].to(dev), d["embedding_gt"].to(dev)
+with torch.no_grad():
+    net(x, e)
+torch.cuda.synchronize()
+
+
+class Rec:
+    def __init__(self, lib):
+        self.lib, self.calls, self.path = lib, [], lib.path
+
+    def call(self, name, *args):
+        self.calls.append((name, args))
+        self.lib.call(name, *args)
+
+
+rec = Rec(lib)
+net._lib_override = rec
+with torch.no_grad():
+    net(x, e)
+torch.cuda.synchronize()
+net._lib_override = None
+SECS = float(os.environ.get("PROBE_SECS", "2.5"))
+samples, stop = [], [False]
+
+
+def sampler():
+    while not stop[0]:
+        try:
+            o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+            pw = re.search(r"Power \(W\):\s*([\d.]+)", o)
+            sc = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", o)
+            if pw:
+                samples.append((float(pw.group(1)), int(sc.group(1)) if sc else 0))
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def measure(fn, label, per=1):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    samples.clear()
+    stop[0] = False
+    th = threading.Thread(target=sampler)
+    th.start()
+    n, t0 = 0, time.time()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    while time.time() - t0 < SECS:
+        for _ in range(20):
+            fn()
+        n += 20
+        torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    stop[0] = True
+    th.join()
+    ms = e0.elapsed_time(e1) / n
+    s = samples[1:] or samples
+    pw = sum(a for a, _ in s) / max(len(s), 1)
+    sc = sum(b for _, b in s) / max(len(s), 1)
+    print(f"{label:22s} x{per}  {ms:8.4f} ms  {pw:6.0f} W  sclk {sc:5.0f} MHz  {ms * pw / 1000:7.3f} J/call  -> {per * ms * pw / 1000:7.3f} J/step", flush=True)
+    return per * ms, per * ms * pw / 1000
+
+
+seen, tot_ms, tot_j = {}, 0.0, 0.0
+count = {}
+for name, _ in rec.calls:
+    count[name] = count.get(name, 0) + 1
+for name, args in rec.calls:
+    if name in seen:
+        continue
+    seen[name] = True
+    a, b = measure(lambda: lib.call(name, *args), name, count[name])
+    tot_ms += a
+    tot_j += b
+print(f"sum over calls: {tot_ms:.3f} ms, {tot_j:.3f} J per step")
+
+
+def fwd():
+    with torch.no_grad():
+        net(x, e)
+
+
+measure(fwd, "whole forward")

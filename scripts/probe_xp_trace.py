@@ -38,3 +38,34 @@ for w, name in enumerate(["workgroup 7", "workgroup n/2+3"]):
     print(name, sys.argv[1:], "ticks per step median %.0f p10 %.0f p90 %.0f | phase H %.0f  phase C %.0f  barrier %.0f" %
           (np.median(step), np.percentile(step, 10), np.percentile(step, 90), np.median(tt[:, 1] - tt[:, 0]),
            np.median(tt[:, 2] - tt[:, 1]), np.median(tt[1:, 0] - tt[:-1, 2])))
+
+# workgroup log of the last forward-direction launch: residency per CU over time
+log = np.zeros(4096 * 4, dtype=np.uint64)
+if lib.raw("lh_probe_xp_wglog_read")(log.ctypes.data_as(ctypes.c_void_p)) == 0:
+    n = (B * T + 15) // 16
+    L = log.reshape(4096, 4)[:n].astype(np.int64)
+    t0, t1, hw, xcc = L[:, 0], L[:, 1], L[:, 2], L[:, 3] & 0xF
+    # HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...
+    cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3
+    key = xcc * 4096 + se * 64 + sh * 32 + cu
+    print("workgroups", n, "distinct (xcc, se, sh, cu):", len(np.unique(key)), " distinct xcc:", len(np.unique(xcc)))
+    span = t1.max() - t0.min()
+    dur = t1 - t0
+    print("launch span ticks %d; workgroup duration ticks median %d p10 %d p90 %d min %d max %d" %
+          (span, np.median(dur), np.percentile(dur, 10), np.percentile(dur, 90), dur.min(), dur.max()))
+    # residency: average number of workgroups alive per CU over the launch span (sampled)
+    ts = np.linspace(t0.min(), t1.max(), 200)
+    alive = [(np.sum((t0 <= t) & (t1 > t))) for t in ts]
+    print("alive workgroups over time (20 samples):", [int(a) for a in alive[5::10]])
+    # co-residency of the per-CU neighbours
+    per = {}
+    for k, a, b in zip(key, t0, t1):
+        per.setdefault(int(k), []).append((int(a), int(b)))
+    mx = []
+    for k, iv in per.items():
+        ev = sorted([(a, 1) for a, b in iv] + [(b, -1) for a, b in iv])
+        c = m = 0
+        for _, dlt in ev:
+            c += dlt; m = max(m, c)
+        mx.append(m)
+    print("max concurrent workgroups per CU: histogram", np.bincount(mx).tolist(), " workgroups per CU: min %d max %d" % (min(len(v) for v in per.values()), max(len(v) for v in per.values())))

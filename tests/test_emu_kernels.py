@@ -72,8 +72,9 @@ def test_streaming_chunks_and_mod_pad(emu_net, oracle_cfg_sd):
 
 
 def test_fused_intra_path_forced_small(emu_net, oracle_cfg_sd):
-    """The large-batch intra path (LSTM + Linear + residual fused, forward launch then accumulating reverse launch),
-    which `Net` only selects from 8192 frames on, forced at a tiny size: 38 frames = 3 sequence tiles, last one ragged."""
+    """The large-batch intra path (k_intra_xp, lh_recur.hip: LSTM + Linear + residual fused, x half of the gates one step
+    ahead, hand-ordered step; forward launch then accumulating reverse launch), which `Net` only selects from 8192 frames
+    on, forced at a tiny size: 38 frames = 3 sequence tiles, last one ragged."""
     cfg, sd = oracle_cfg_sd
     B, T = 2, 19
     d = synth.batch([3, 4], 128 * T + 64)
@@ -91,9 +92,9 @@ def test_fused_intra_path_forced_small(emu_net, oracle_cfg_sd):
         assert (fm[k] - fo[k]).abs().max() < TOL, k
 
 
-def test_pipelined_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
-    """k_intra_xp (lh_recur.hip: x half of the gates one step ahead, hand-ordered step) selected with lh_set_tuning(2, 1)
-    at the same tiny size: 38 frames = 3 sequence tiles, last one ragged, both directions."""
+def test_previous_fused_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
+    """k_ln_lstm_lin<1> (the fused intra kernel before k_intra_xp became the default; kept for A/B runs, selected with
+    lh_set_tuning(2, 2)) at the same tiny size: 38 frames = 3 sequence tiles, last one ragged, both directions."""
     cfg, sd = oracle_cfg_sd
     lib = emu_net._lib_override
     B, T = 2, 19
@@ -102,7 +103,7 @@ def test_pipelined_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
     saved = emu_net.fuse_intra_min_frames
     emu_net.fuse_intra_min_frames = 1
-    lib.call("lh_set_tuning", 2, 1)
+    lib.call("lh_set_tuning", 2, 2)
     try:
         y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
     finally:
