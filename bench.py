@@ -61,9 +61,68 @@ KERNEL_WORK = {
 LAUNCHES_PER_CALL = {"lh_intra_block": 2, "lh_embed_proj_ln": 2, "lh_metric_sums": 2}
 # the kernel function behind each call, as rocprofv3 names it (profiles/*kernel_stats*.csv)
 KERNEL_NAME = {"lh_inter_matvec": "k_inter_matvec", "lh_intra_stream": "k_intra_stream",
-               "lh_intra_block": "k_ln_lstm_lin<1> (intra grid)", "lh_inter_block": "k_lstm_lin8p",
+               "lh_intra_block": "k_intra_xp", "lh_inter_block": "k_lstm_lin8p",
                "lh_local_attn": "k_local_attn", "lh_qkv_proj_ln": "k_qkv_proj_ln", "lh_proj_ln_res": "k_proj_ln_res",
                "lh_deconv_istft": "k_deconv_istft", "lh_stft_conv_in": "k_stft_conv_in"}
+
+
+PACKAGE_POWER_CAP_W = 1400.0          # MI355X package power limit (rocm-smi --showmaxpower on the bench boxes)
+MEASURED_MFMA16_TFLOPS_AT_CAP = 2310.0   # pure v_mfma_f32_16x16x32_f16 stream, every CU, non-trivial operands: 1280 W at
+                                          # 2.33 GHz (profiles/r03a_power_per_instruction.txt); 32x32x16: 2000 at 1.91 GHz
+
+
+def power_leg(step_fn, seconds=2.0):
+    """Package power / shader clock while `step_fn` runs back to back for `seconds` (rocm-smi sampled from a second
+    thread; the timed region of the bench is far too short for a sample).  The whole path runs at the package power
+    limit, so joules per step — not cycles — is what bounds it."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                pw = re.search(r"Power \(W\):\s*([\d.]+)", o)
+                sc = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", o)
+                if pw:
+                    samples.append((float(pw.group(1)), int(sc.group(1)) if sc else 0))
+            except Exception:            # no rocm-smi on this box: the leg reports null
+                return
+
+    try:
+        for _ in range(3):
+            step_fn()
+        torch.cuda.synchronize()
+        th = threading.Thread(target=sampler)
+        th.start()
+        n, t0 = 0, time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                step_fn()
+            n += 10
+            torch.cuda.synchronize()
+        e1.record()
+        torch.cuda.synchronize()
+        stop[0] = True
+        th.join()
+        s_ = samples[1:] or samples
+        if not s_:
+            return None
+        ms = e0.elapsed_time(e1) / n
+        pw = sum(a for a, _ in s_) / len(s_)
+        sc = sum(b for _, b in s_) / len(s_)
+        return {"package_w_avg": pw, "package_w_max": max(a for a, _ in s_), "package_cap_w": PACKAGE_POWER_CAP_W,
+                "frac_of_cap": pw / PACKAGE_POWER_CAP_W, "sclk_mhz_avg": sc, "samples": len(s_), "ms_per_step": ms,
+                "joules_per_step": pw * ms * 1e-3, "seconds": seconds,
+                "note": "steps run back to back for `seconds`, rocm-smi sampled concurrently; per-call figures: "
+                        "profiles/r03*_power_by_call*.txt"}
+    except Exception as e:               # never lose the headline line to the side measurement
+        stop[0] = True
+        return {"error": repr(e)[:200]}
 
 
 def cpu_baseline(sample_clips=4, repeats=2, budget_s=120.0):
@@ -352,12 +411,21 @@ def dry_run_cpu(args, rank, world):
     for _ in range(args.warmup):
         step()
     elapsed, _, sums = timed_region(step, args.steps, dist if world > 1 else None, "cpu", lambda: None)
+    ranks_seen, allreduce_us = world, None
+    if world > 1:                        # same fields as the GPU line: the group's own size, the exchange step by itself
+        ranks_seen = dist.get_world_size()
+        buf = sums.clone()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        allreduce_us = (time.perf_counter() - t0) / 20 * 1e6
     if rank == 0:
         print(json.dumps({"metric": "DRY RUN (gloo, no separator): plumbing only", "value": world * B * args.steps / elapsed,
                           "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                           "config": {"workload": "plumbing dry run", "batch_per_gpu": B, "global_batch": world * B},
+                          "n_ranks_seen": ranks_seen, "allreduce_32B_us": allreduce_us,
                           "metric_sums": [float(v) for v in sums.tolist()]}))
     if world > 1:
         dist.destroy_process_group()
@@ -470,6 +538,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE configs[2] = 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the 2 s package-power leg (N = 1 only)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="gloo / host-tensor dry run of the N>1 plumbing (no GPU, no model)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` measurements (offline B=1 / B=256, streaming, embedder, exact-fp32 contrast)")
@@ -560,6 +629,26 @@ def main():
         elapsed, local_elapsed, (y, sums) = timed_region(step, args.steps, dist, dev, torch.cuda.synchronize)
         prof, net._prof, net._prof_only = net._prof, None, None
     log(f"timed region: {local_elapsed * 1e3 / args.steps:.3f} ms/step (max over ranks {elapsed * 1e3 / args.steps:.3f})")
+    # N > 1: the exchange step by itself — 100 all-reduces of the 32-byte metric vector on RCCL, HIP events on this rank
+    allreduce_us, ranks_seen = None, world
+    if dist is not None:
+        ranks_seen = dist.get_world_size()
+        buf = sums.clone()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_us = e0.elapsed_time(e1) * 10.0
+    power = None
+    if world == 1 and not args.no_power:
+        with torch.no_grad():
+            power = power_leg(step)
+        log(f"power leg: {power}")
 
     # HIP-event durations (this rank): the dominant call live over the timed region, the others from the instrumented
     # warm-up step
@@ -572,11 +661,12 @@ def main():
         value = total_clips * FRAMES_PER_CLIP / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         w = KERNEL_WORK[dom]
-        traffic, traffic_src = None, None
+        traffic, traffic_src, tj_dom = None, None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes per launch from the PMC passes
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if tj.get("batch_per_gpu") == B and dom in tj.get("kernels", {}):
+                tj_dom = tj["kernels"][dom]
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]    # per kernel launch (rocprofv3 dispatch)
                 traffic_src = ("profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                "bench, committed with the kernels; source profile: %s) — not re-measured in this run"
@@ -602,6 +692,17 @@ def main():
         # also separates the dispatches): the figure to hold against profiles/*kernel_stats*.csv
         roof["avg_launch_ms_instrumented_step"] = breakdown[dom]["avg_ms"] / lpc
         roof["share_of_gpu_time"] = kern[dom]["avg_ms"] * breakdown[dom]["launches"] / gpu_ms
+        # the same kernel against the other roofline, and against what the chip sustains under its 1400 W package limit
+        roof["frac_hbm"] = w["bytes"] * B / (kern[dom]["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+        if w["bound"] == "mfma" and net.gemm_mode == "f16x3":
+            roof["executed_fp16_tflops"] = 3.0 * roof["achieved"]
+            roof["frac_of_measured_mfma_rate_at_power_cap"] = 3.0 * roof["achieved"] / MEASURED_MFMA16_TFLOPS_AT_CAP
+        roof["limited_by"] = ("package power: this call draws ~1375 W of the 1400 W limit at ~1.75-1.9 GHz "
+                              "(profiles/r03b_power_by_call_b32.txt); MFMA issue is 30 % of its energy")
+        if tj_dom is not None:
+            for k_ in ("mfma_busy", "valu_busy"):
+                if k_ in tj_dom:
+                    roof[k_] = tj_dom[k_]
         out = {
             "metric": "frames_per_sec (5 s 16 kHz binaural clips, 625 STFT frames each, offline forward)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -618,6 +719,8 @@ def main():
                            "algorithmic_hbm_gbs": (BYTES_PER_CLIP * B + WEIGHT_BYTES) * world * args.steps / elapsed / 1e9,
                            "frac_hbm_peak": (BYTES_PER_CLIP * B + WEIGHT_BYTES) * world * args.steps / elapsed / 1e9 / (PEAK_HBM_GBS * world)},
             "roofline": roof,
+            "power": power,
+            "n_ranks_seen": ranks_seen, "allreduce_32B_us": allreduce_us,
             # ms per step of each C-ABI call: the dominant one live over the timed region, the rest from the instrumented
             # warm-up step
             "kernels_ms_per_step": {k: v["avg_ms"] * breakdown[k]["launches"]

@@ -27,18 +27,18 @@ ubench)             # per-SIMD issue model micro-benchmark (scripts/ubench/gen_i
 check)              # GPU parity suite + bench lines (batch 32, batch 1, streaming)
     timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
     for a in "--batch 32" "--batch 1" "--mode stream"; do
-        timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline $a > gpurun_out/bench_chk.json 2>> gpurun_out/bench.err
+        timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-power $a > gpurun_out/bench_chk.json 2>> gpurun_out/bench.err
         bench_line gpurun_out/bench_chk.json "$a"
     done ;;
 ab)                 # same-box A/B of library builds: LIBS="_lookonce_hip_x.so _lookonce_hip.so" BATCH=32 REPS=2
     for rep in $(seq ${REPS:-2}); do for lib in ${LIBS:-_lookonce_hip.so}; do for b in ${BATCH:-32}; do
-        LOOKONCE_HIP_LIB=$R/lookoncetohear_amd/$lib timeout 200 python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-secondary --batch $b ${BENCH_ARGS:-} > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
+        LOOKONCE_HIP_LIB=$R/lookoncetohear_amd/$lib timeout 200 python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-secondary --no-power --batch $b ${BENCH_ARGS:-} > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
         bench_line gpurun_out/bench_ab.json "$lib B=$b"
     done; done; done ;;
 tunes)              # same-box A/B of lh_set_tuning switches: TUNES="_ 5=1 2=1" (_ = defaults) BATCH=32 REPS=2
     for rep in $(seq ${REPS:-2}); do for t in ${TUNES:-_}; do for b in ${BATCH:-32}; do
         ta=""; [ "$t" != "_" ] && ta="--tune $t"
-        timeout 200 python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-secondary --batch $b $ta > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
+        timeout 200 python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-secondary --no-power --batch $b $ta > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
         bench_line gpurun_out/bench_ab.json "tune $t B=$b"
     done; done; done ;;
 lab)                # recurrent-kernel lab: LIBS="_lookonce_hip.so _lookonce_hip_x.so" TUNES="_ 2=1 5=1" (scripts/lab_recur.py)

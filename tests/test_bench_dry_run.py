@@ -28,10 +28,11 @@ def test_bench_plumbing_world2_gloo():
     from lookoncetohear_amd.metrics import metric_sums
     two = _run(2)
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["dry_run"] and two["scaling"] == "weak"
+    assert two["n_ranks_seen"] == 2 and two["allreduce_32B_us"] > 0          # the group's own size + the exchange step alone
     d = synth.batch([0, 1, 2, 3], 4000)                       # rank 0: utterances 0, 1; rank 1: 2, 3
     ref = metric_sums(0.6 * d["target"] + 0.4 * d["mixture"], d["mixture"], d["target"], d["embedding_gt"][:, 0],
                       d["embedding_gt"][:, 0])
     assert two["metric_sums"][3] == 4.0
     assert torch.allclose(torch.tensor(two["metric_sums"], dtype=torch.float64), ref, rtol=1e-9, atol=1e-9)
     one = _run(1)
-    assert one["n_gpus"] == 1 and one["metric_sums"][3] == 2.0
+    assert one["n_gpus"] == 1 and one["metric_sums"][3] == 2.0 and one["n_ranks_seen"] == 1
