@@ -28,8 +28,29 @@ enum {
     LH_OK = 0,
     LH_ERR_ARG = 1,         /* null pointer / non-positive size */
     LH_ERR_UNSUPPORTED = 2, /* shape constants differ from the compiled configuration */
-    LH_ERR_LAUNCH = 3       /* hipGetLastError() != hipSuccess after the launch */
+    LH_ERR_LAUNCH = 3,      /* hipGetLastError() != hipSuccess after the launch */
+    LH_ERR_RANGE = 4        /* lh_range_status only: a non-finite output sample was produced since the last check */
 };
+
+/* Range contract of the split-precision ("f16x3") arithmetic.  Operands are carried as fp16 hi + fp16 lo, so every value
+ * a kernel SPLITS must satisfy |v| < 65504.  LayerNorm outputs, hidden states, attention rows and weights always do; the
+ * un-normalised residual stream (read by lh_qkv_proj_ln, lh_proj_ln_res, lh_deconv_istft, and the waveform / spectrum in
+ * lh_stft_conv_in) does only while the network's activations stay below that bound — in EVERY gemm mode, because
+ * LH_GEMM_F32 only switches the two recurrences to exact fp32 (the frame kernels are split-precision always).  Beyond the
+ * bound hi becomes inf, the frame's products NaN, and the NaN reaches the output waveform; lh_deconv_istft then sets a
+ * sticky per-device flag.  (A NaN / inf in the inputs raises the same flag.)
+ *   lh_range_status: copies the flag to the host on `stream`, WAITS for the stream, clears the flag; LH_OK, or
+ *                    LH_ERR_RANGE when it was set.  The one entry point that synchronises: call it once per forward.
+ *   lh_range_flag_copy: asynchronous copy of the flag to `host_pinned` (4 bytes of pinned host memory) on `stream`, no
+ *                    wait, no clear — capturable in a HIP graph (the streaming host polls the word one chunk later).
+ *   lh_range_flag_clear: asynchronous clear on `stream`.
+ *   lh_selftest_fp16_subnormal: runs one v_mfma_f32_16x16x32_f16 on fp16-subnormal operands (the un-rescaled lo halves
+ *                    rely on the matrix core taking them at full value); LH_OK, or LH_ERR_UNSUPPORTED when they are
+ *                    flushed.  Synchronises. */
+int lh_range_status(lh_stream_t stream);
+int lh_range_flag_copy(void* host_pinned, lh_stream_t stream);
+int lh_range_flag_clear(lh_stream_t stream);
+int lh_selftest_fp16_subnormal(lh_stream_t stream);
 
 /* Contraction arithmetic of the recurrent kernels (argument `mode`):
  *   LH_GEMM_F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32); w_pk = fp32 image  [dirs][4][4][32][64]

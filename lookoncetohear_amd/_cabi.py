@@ -11,7 +11,7 @@ from ctypes import c_int, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _P, _I = c_void_p, c_int
 # name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
@@ -40,12 +40,16 @@ SIGNATURES = {
     "lh_emb_head": [_P] * 7 + [_I, _I, _P],
     "lh_render_binaural": [_P] * 8 + [_I, _I, _I, _I, _P],
     "lh_metric_sums": [_P] * 8 + [_I, _I, _I, _P],
+    "lh_range_status": [_P],
+    "lh_range_flag_copy": [_P, _P],
+    "lh_range_flag_clear": [_P],
+    "lh_selftest_fp16_subnormal": [_P],
     "lh_comm_unique_id": [_P],
     "lh_comm_init": [_P, _I, _I, _P],
     "lh_allreduce_f64": [_P, _P, _I, _P],
     "lh_comm_destroy": [_P],
 }
-ERRORS = {1: "LH_ERR_ARG", 2: "LH_ERR_UNSUPPORTED", 3: "LH_ERR_LAUNCH"}
+ERRORS = {1: "LH_ERR_ARG", 2: "LH_ERR_UNSUPPORTED", 3: "LH_ERR_LAUNCH", 4: "LH_ERR_RANGE"}
 
 
 class Lib:

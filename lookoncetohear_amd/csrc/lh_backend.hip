@@ -33,6 +33,8 @@ __device__ unsigned long long lh_be_trace_buf[32];
 #endif
 
 // grid = persistent (<= 256), block 512
+__device__ unsigned lh_range_flag = 0;        // set when a non-finite output sample is stored (range contract, lookonce_hip.h)
+
 __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict__ y, const float* __restrict__ dbuf_in,
                                                         float* __restrict__ dbuf_out, const float* __restrict__ ibuf_in,
                                                         float* __restrict__ ibuf_out, const _Float16* __restrict__ wd_pk,
@@ -301,12 +303,15 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
         BE_STAMP(9);
 
         // overlap-add: output frame t (samples 128t..128t+127) = fr[t+1][0:128] + fr[t][128:192]
+        bool bad = false;
         for (int i = tid; i < nt_out * NSRC * HOP; i += BE_NT) {
             const int n = i % HOP, s = (i / HOP) % NSRC, jt = i / (HOP * NSRC);
             float v = frs[jt + 1][s][n];
             if (n < NFFT - HOP) v += frs[jt][s][n + HOP];
             wave_out[((long)b * NSRC + s) * L + (long)(t0 + jt) * HOP + n] = v;
+            bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;      // inf / NaN: the fp16 split overflowed upstream
         }
+        if (bad) atomicOr(&lh_range_flag, 1u);        // sticky, read by lh_range_status (include/lookonce_hip.h)
         __syncthreads();
         // frs lived in the hi A images: their pad rows (97..111 feed dropped outputs) must hold finite numbers again —
         // only those: the 97 real rows are rewritten by the staging of the next frames
@@ -353,4 +358,53 @@ extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float
                        deconv_buf_in, deconv_buf_out, istft_buf_in, istft_buf_out, (const _Float16*)wdec_pk, bdec,
                        (const _Float16*)wfb_dec, wave_out, B, T, runs_per_b);
     return check_launch();
+}
+
+// ---- range contract of the split-precision arithmetic (include/lookonce_hip.h)
+extern "C" int lh_range_flag_copy(void* host_pinned, lh_stream_t stream) {
+    if (!host_pinned) return LH_ERR_ARG;
+    return hipMemcpyFromSymbolAsync(host_pinned, HIP_SYMBOL(lh::lh_range_flag), sizeof(unsigned), 0, hipMemcpyDeviceToHost,
+                                    (hipStream_t)stream) == hipSuccess ? LH_OK : LH_ERR_LAUNCH;
+}
+extern "C" int lh_range_flag_clear(lh_stream_t stream) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(lh::lh_range_flag)) != hipSuccess) return LH_ERR_LAUNCH;
+    return hipMemsetAsync(p, 0, sizeof(unsigned), (hipStream_t)stream) == hipSuccess ? LH_OK : LH_ERR_LAUNCH;
+}
+extern "C" int lh_range_status(lh_stream_t stream) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(lh::lh_range_flag), sizeof(unsigned), 0, hipMemcpyDeviceToHost,
+                                 (hipStream_t)stream) != hipSuccess)
+        return LH_ERR_LAUNCH;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return LH_ERR_LAUNCH;
+    if (!v) return LH_OK;
+    if (lh_range_flag_clear(stream) != LH_OK) return LH_ERR_LAUNCH;
+    return LH_ERR_RANGE;
+}
+
+namespace lh {
+__global__ void k_selftest_subnormal(float* out) {
+    f16x8 a, b, b2;
+    for (int i = 0; i < 8; ++i) {
+        a[i] = (_Float16)9.5367431640625e-07f;      // 2^-20: subnormal in fp16
+        b[i] = (_Float16)1.0f;
+        b2[i] = (_Float16)6.103515625e-05f;         // 2^-14: smallest normal
+    }
+    f32x4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);        // 32 * 2^-20
+    c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2, c2, 0, 0, 0);     // 32 * 2^-34
+    if (threadIdx.x == 0) { out[0] = c[0]; out[1] = c2[0]; }
+}
+}  // namespace lh
+extern "C" int lh_selftest_fp16_subnormal(lh_stream_t stream) {
+    float* d = nullptr;
+    if (hipMalloc(&d, 2 * sizeof(float)) != hipSuccess) return LH_ERR_LAUNCH;
+    hipLaunchKernelGGL(lh::k_selftest_subnormal, dim3(1), dim3(64), 0, (hipStream_t)stream, d);
+    float h[2] = {0.f, 0.f};
+    const bool ok = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+                    hipStreamSynchronize((hipStream_t)stream) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return LH_ERR_LAUNCH;
+    return (h[0] == 32.0f * 9.5367431640625e-07f && h[1] == 32.0f * 9.5367431640625e-07f * 6.103515625e-05f)
+               ? LH_OK : LH_ERR_UNSUPPORTED;
 }

@@ -10,6 +10,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "lh_common.h"
 
@@ -28,25 +29,29 @@ struct Rccl {
     bool ok = false;
 };
 
-Rccl& rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+void bind(Rccl& r) {
     const char* names[] = {getenv("LOOKONCE_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        if (!n || !*n) continue;
-        // RTLD_NOLOAD first: reuse the copy the process already mapped (e.g. PyTorch's) under the same soname
-        r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.so) break;
-    }
-    if (!r.so) return r;
+    // First pass over ALL names with RTLD_NOLOAD: reuse the copy the process already mapped (PyTorch-ROCm bundles its own
+    // librccl.so; /opt/rocm ships librccl.so.1 — trying to LOAD the first name before LOOKING for the second would map a
+    // second RCCL next to torch's).  Only when none is mapped does the second pass really load one.
+    for (int pass = 0; pass < 2 && !r.so; ++pass)
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            r.so = dlopen(n, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD) : (RTLD_NOW | RTLD_LOCAL));
+            if (r.so) break;
+        }
+    if (!r.so) return;
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.so, "ncclAllReduce"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
     r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
+}
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { bind(r); });          // thread-safe: several host threads may create communicators
     return r;
 }
 

@@ -419,7 +419,6 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
     __shared__ __attribute__((aligned(16))) float ls[2 * NS * LSP];
-    __shared__ __attribute__((aligned(16))) float hf[NS * LSP];                   // fp32 copy of the final hidden state
 #if defined(LH_PROBE_TRACE)
     __shared__ unsigned long long tr[128 * 4];
     const int tr_slot = blockIdx.x == 7 ? 0 : (blockIdx.x == gridDim.x - 9 ? 1 : -1);
@@ -989,6 +988,9 @@ static int launch_lstm_lin(const float* x, const void* w_pk, const float* b_sum,
                            const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep,
                            int sdiv, int so, int si, int ps, int dir, int accumulate, hipStream_t st) {
     constexpr int NS = 16 * MT;
+    // k_ln_lstm_lin serves the intra pass (zero initial state, no state out): it never writes hN / cN, so a caller that
+    // asks for them must be refused instead of handed uninitialised memory
+    if (h0 || c0 || hN || cN) return LH_ERR_ARG;
     hipLaunchKernelGGL((k_ln_lstm_lin<MT>), dim3((nseq + NS - 1) / NS), dim3(256), 0, st, x, (const _Float16*)w_pk, b_sum,
                        (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate,
                        g_dephase);

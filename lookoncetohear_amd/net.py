@@ -149,9 +149,15 @@ class Net(nn.Module):
         self.E = math.ceil(512 * 1.0 / self.n_freqs)
         self.V_dim = D // L
         self.tfgridnet = _TFGridNetParams(self.nfft, stft_chunk_size, num_ch, num_src, D, B, H, L, embed_dim)
-        # contraction arithmetic of the recurrent kernels: "f16x3" = split-precision fp16 MFMA (hi/lo operands,
-        # ~22 mantissa bits, ~5x the fp32-MFMA rate), "f32" = exact fp32 MFMA.  LOOKONCE_GEMM overrides.
+        # contraction arithmetic of the two RECURRENCES: "f16x3" = split-precision fp16 MFMA (hi/lo operands, ~22 mantissa
+        # bits, ~5x the fp32-MFMA rate), "f32rec" = exact fp32 MFMA in the intra / inter LSTMs (the name says what it
+        # covers: the frame kernels — STFT / conv, Q/K/V, attention, projection, deconv / iSTFT — are split-precision in
+        # every mode; "f32" is accepted as the old spelling).  LOOKONCE_GEMM overrides.
         self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
+        # range contract of the split-precision kernels (include/lookonce_hip.h): values they split must stay below 65504.
+        # With `range_check` every forward ends with lh_range_status (one 4-byte copy + a wait on the launch stream) and
+        # raises instead of returning inf / NaN; a `Streamer` polls the same flag one chunk late.
+        self.range_check = os.environ.get("LOOKONCE_RANGE_CHECK", "1") != "0"
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
         self.fuse_intra_min_frames = 8192
@@ -351,8 +357,8 @@ class Net(nn.Module):
                 taps["Z0"], taps["G"] = xa.clone(), ws["gain"].clone()
 
             rows = Bn * T * F_
-            if self.gemm_mode not in ("f32", "f16x3"):
-                raise ValueError(f"gemm_mode must be 'f32' or 'f16x3', got {self.gemm_mode!r}")
+            if self.gemm_mode not in ("f32rec", "f32", "f16x3"):
+                raise ValueError(f"gemm_mode must be 'f16x3' or 'f32rec', got {self.gemm_mode!r}")
             mode = 1 if self.gemm_mode == "f16x3" else 0
             wkey, bkey = ("_w16", "_b16") if mode else ("_w", "_b")
             for i in range(self.n_blocks):
@@ -427,7 +433,21 @@ class Net(nn.Module):
                      P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), Bn, T, st)
             if want_state:
                 state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
+            if self.range_check:
+                self._raise_on_range(lib_, st)
         return y, (state if want_state else None)
+
+    @staticmethod
+    def _raise_on_range(lib, stream):
+        rc = lib.raw("lh_range_status")(stream)
+        if rc == 4:
+            raise RuntimeError(
+                "LH_ERR_RANGE: the forward produced non-finite samples. The split-precision (fp16 hi + lo) kernels need "
+                "every value they split below 65504; the un-normalised residual stream of this network / input exceeded it "
+                "(or the input held inf / NaN). No arithmetic mode of this library covers that range: gemm_mode='f32rec' "
+                "only makes the two recurrences exact fp32 (include/lookonce_hip.h, range contract).")
+        if rc != 0:
+            raise RuntimeError(f"lh_range_status failed: {_cabi.ERRORS.get(rc, rc)}")
 
     # ------------------------------------------------------------------------------------------------
     # streaming fast path (Streamer)
@@ -519,6 +539,11 @@ class Streamer:
         self.pos = z(1, dtype=torch.int32)
         self.gain = z(B, F_, C_)
         self.gain_raw = z(B, F_ * C_)
+        # range flag of the split-precision kernels, copied into pinned host memory at the end of every chunk (part of the
+        # captured graph) and looked at when the NEXT chunk arrives — the consumer has synchronised on the output by then
+        self.range_word = torch.zeros(1, dtype=torch.int32)
+        if dev.type == "cuda":
+            self.range_word = self.range_word.pin_memory()
         self.parity = 0
         self.graphs = None
         self.graph = None
@@ -528,6 +553,8 @@ class Streamer:
         with torch.no_grad(), _device_of(self.chunk):
             self._pk = net._weights(dev)
             self._pack_key = net._pack_key
+            self._n_steps = 0
+            self._stamp = self._version_stamp()
             self._ws = net._workspace(B, 1, dev)
             net._ws.pop((B, 1, str(dev)), None)          # private to this streamer from now on
         if use_graph and dev.type == "cuda":
@@ -546,6 +573,11 @@ class Streamer:
             self.graph = self.graphs[0]
             self.reset()
 
+    def _version_stamp(self) -> int:
+        if self.net._blob is not None:
+            return 0
+        return sum(t._version for t in self.net.parameters()) + sum(t._version for t in self.net.buffers())
+
     def _body(self, k: int):
         with _device_of(self.chunk):
             self.net._stream_chunk(self.chunk, self.gain, self.sets[k], self.sets[k ^ 1], self.rings, self.pos, self.out,
@@ -553,6 +585,9 @@ class Streamer:
             # ring slot counter, kept in [0, window): an ever-growing int32 would go negative after 2^31 chunks and C's
             # `%` would then index before the ring
             self.pos.add_(1).remainder_(self.net.local_atten_len)
+            if self.net.range_check:
+                st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+                self.net._lib(self.chunk).call("lh_range_flag_copy", self.range_word.data_ptr(), st)
 
     def reset(self):
         for st in self.sets:
@@ -574,9 +609,24 @@ class Streamer:
         # O(1) staleness check (re-deriving the pack key walks all 130 parameters: ~0.1 ms of host time per 8 ms chunk):
         # any `Net` call after a parameter change re-packs and replaces `net._packed`.  The streamer owns references to
         # the images its graphs point into, so a stale streamer is never unsafe, only out of date.
-        if self.net._packed is not self._pk:
+        net = self.net
+        cur = net._blob[1] if net._blob is not None else net._packed      # blob-only hosts (`from_packed`) never re-pack
+        if cur is not self._pk:
             raise RuntimeError("the Net's parameters changed after this Streamer was built (its HIP graphs hold pointers "
                                "into the old packed weights): create a new streamer with net.make_streamer(...)")
+        # ... and a parameter updated IN PLACE (optimizer step, load_state_dict) without any other `Net` call in between
+        # would replay silently on the old images: a cheap version stamp (sum of the tensors' version counters) every
+        # 64th chunk catches it within half a second of audio
+        if int(self.range_word[0]) != 0:
+            self.range_word.zero_()
+            st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+            net._lib(self.chunk).call("lh_range_flag_clear", st)
+            raise RuntimeError("LH_ERR_RANGE: an earlier chunk produced non-finite samples (fp16 split overflow of the "
+                               "residual stream, or inf / NaN in the input); reset() the streamer")
+        self._n_steps += 1
+        if net._blob is None and (self._n_steps & 63) == 0 and self._version_stamp() != self._stamp:
+            raise RuntimeError("a parameter of the Net was modified in place after this Streamer was built: create a new "
+                               "streamer with net.make_streamer(...)")
         self.chunk.copy_(chunk)
         with torch.no_grad():
             if self.graphs is not None:

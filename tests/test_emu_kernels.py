@@ -266,6 +266,28 @@ def test_streamer_ring_and_pingpong(emu_net, oracle_cfg_sd):
     assert torch.equal(torch.cat(outs2, -1), torch.cat(outs[:3], -1))
 
 
+def test_range_contract_raises_instead_of_returning_nan(emu_net):
+    """Range contract of the split-precision kernels (include/lookonce_hip.h): an input beyond the fp16 range of the hi
+    halves (|v| >= 65504) turns the frame's products into NaN; the back end flags the non-finite samples and
+    `Net.forward` raises LH_ERR_RANGE instead of returning them.  The flag is cleared by the read: the next forward is
+    clean.  The `Streamer` polls the same flag one chunk late."""
+    d = synth.batch([1], 128 * 3)
+    big = d["mixture"] * 1e6
+    with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
+        emu_net(big, d["embedding_gt"])
+    y = emu_net(d["mixture"], d["embedding_gt"])
+    assert torch.isfinite(y).all()
+    st = emu_net.make_streamer(1, "cpu", use_graph=False)
+    st.set_embedding(d["embedding_gt"][:, 0])
+    st.step(d["mixture"][:, :, :192])
+    st.step(big[:, :, :192])                              # produces NaN; noticed when the next chunk arrives
+    with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
+        st.step(d["mixture"][:, :, :192])
+    st.reset()
+    assert torch.isfinite(st.step(d["mixture"][:, :, :192])).all()
+    assert emu_net._lib_override.raw("lh_selftest_fp16_subnormal")(None) == 0
+
+
 def test_cabi_argument_errors(emu_net):
     lib = emu_net._lib_override
     assert lib.raw("lh_check_config")(192, 128, 2, 64, 3, 64, 4, 50, 2, 256) == 0
@@ -315,3 +337,35 @@ def test_packed_blob_is_a_sufficient_weight_source(emu_net, tmp_path):
     d = synth.batch([2], 128 * 3)
     with torch.no_grad():
         assert torch.equal(blob_net(d["mixture"], d["embedding_gt"]), emu_net(d["mixture"], d["embedding_gt"]))
+    # the blob-only host must also stream (real-time use): same chunks through both streamers, bit-equal
+    d = synth.batch([4], 128 * 3 + 64)
+    outs = []
+    for net in (emu_net, blob_net):
+        st = net.make_streamer(1, "cpu", use_graph=False)
+        st.set_embedding(d["embedding_gt"][:, 0])
+        outs.append(torch.cat([st.step(d["mixture"][:, :, i * 128:i * 128 + 192]).clone() for i in range(3)], -1))
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_streamer_refuses_stale_weights(emu_net):
+    """A `Streamer` holds pointers into the packed weights it was built with: after a re-pack (any `Net` call following a
+    parameter change) the next chunk raises; after an in-place update with no other call in between, the version stamp
+    checked every 64th chunk does."""
+    d = synth.batch([4], 128 * 2 + 64)
+    st = emu_net.make_streamer(1, "cpu", use_graph=False)
+    st.set_embedding(d["embedding_gt"][:, 0])
+    st.step(d["mixture"][:, :, :192])
+    p = next(emu_net.parameters())
+    keep = p.detach().clone()
+    try:
+        with torch.no_grad():
+            p.add_(0.0)                                   # in place: version counter moves, `_packed` does not
+        st._n_steps = 63
+        with pytest.raises(RuntimeError, match="modified in place"):
+            st.step(d["mixture"][:, :, :192])
+        emu_net(d["mixture"][:, :, :320], d["embedding_gt"])      # any Net call re-packs
+        with pytest.raises(RuntimeError, match="parameters changed"):
+            st.step(d["mixture"][:, :, :192])
+    finally:
+        with torch.no_grad():
+            p.copy_(keep)

@@ -41,7 +41,7 @@ def nets(oracle_cfg_sd):
     assert torch.cuda.is_available()
     _cabi.load()
     _, sd = oracle_cfg_sd
-    return {"f16x3": _make(sd), "f16x3-unfused": _make(sd, fuse=False), "f32": _make(sd, gemm="f32")}
+    return {"f16x3": _make(sd), "f16x3-unfused": _make(sd, fuse=False), "f32": _make(sd, gemm="f32rec")}
 
 
 @pytest.mark.parametrize("mode", ["f16x3-unfused", "f32"])
@@ -126,32 +126,46 @@ def _scaled_weights(sd, s):
 
 
 def test_fp16_range_stress_of_the_split_precision_path(oracle_cfg_sd):
-    """Where does "f16x3" leave the 1e-3 budget?  The hi half of the split is an fp16: |v| > 65504 becomes inf
-    (lh_split.h, lh_lstm.hip split_f16).  With random-init weights the residual stream peaks at O(10); the table printed
-    (and written to gpurun_out/range_stress.json on the GPU box) shows the error relative to the output amplitude as
-    the stream is scaled up.  Asserted: inside budget up to x64 (peak ~1e3), and the exact-fp32 recurrences agree."""
+    """Where does "f16x3" leave the 1e-3 budget, and what happens beyond it?  The hi half of the split is an fp16:
+    |v| > 65504 becomes inf (lh_split.h).  With random-init weights the residual stream peaks at O(10); the table printed
+    (and written to gpurun_out/range_stress.json on the GPU box) shows the error relative to the output amplitude as the
+    stream is scaled UP (x8 .. x32768: overflow of hi) and DOWN (x1/64, x1/4096: lo halves turn into fp16 subnormals and
+    then vanish, hi keeps 11 bits of a small number).  Asserted: inside the budget from x1/4096 to x64 in both modes; from
+    x4096 on (residual peak 8e4 > 65504) the forward RAISES (LH_ERR_RANGE, the range contract of include/lookonce_hip.h)
+    in both modes — "f32rec" only switches the recurrences to exact fp32 — instead of returning inf."""
     cfg, sd = oracle_cfg_sd
     d = synth.batch([40, 41], 16000)
     x, e = d["mixture"], d["embedding_gt"]
+    assert _cabi.load().raw("lh_selftest_fp16_subnormal")(None) == 0         # the matrix core keeps fp16 subnormals
     rows = []
-    for s in (1.0, 8.0, 64.0, 512.0, 4096.0, 32768.0):
+    for s in (1.0 / 4096, 1.0 / 64, 1.0, 8.0, 64.0, 512.0, 4096.0, 32768.0):
         sds = _scaled_weights(sd, s)
         taps = {}
         yo = O.forward(cfg, sds, x, e, dtype=torch.float64, fast_lstm=True, taps=taps)
         amp = float(yo.abs().max())
         peak = max(float(v.abs().max()) for k, v in taps.items() if k.endswith(".out") or k == "Z0")
         res = {}
-        for mode in ("f16x3", "f32"):
+        for mode in ("f16x3", "f32rec"):
             net = _make(sds, gemm=mode)
-            y = net(x.to(DEV), e.to(DEV))
-            res[mode] = float("inf") if not torch.isfinite(y).all() else _err(y, yo) / amp
-        rows.append(dict(scale=s, residual_peak=peak, out_amp=amp, rel_err_f16x3=res["f16x3"], rel_err_f32=res["f32"]))
+            try:
+                y = net(x.to(DEV), e.to(DEV))
+                assert torch.isfinite(y).all()                       # a non-finite result must have raised
+                res[mode] = _err(y, yo) / amp
+            except RuntimeError as ex:
+                assert "LH_ERR_RANGE" in str(ex)
+                res[mode] = "LH_ERR_RANGE"
+        rows.append(dict(scale=s, residual_peak=peak, out_amp=amp, rel_err_f16x3=res["f16x3"], rel_err_f32rec=res["f32rec"]))
         print(rows[-1])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "range_stress.json"), "w"), indent=1)
     for r in rows:
         if r["scale"] <= 64:
-            assert r["rel_err_f16x3"] < NORTH_STAR_TOL and r["rel_err_f32"] < NORTH_STAR_TOL, r
+            assert r["rel_err_f16x3"] < NORTH_STAR_TOL and r["rel_err_f32rec"] < NORTH_STAR_TOL, r
+        if r["residual_peak"] > 65504:
+            assert r["rel_err_f16x3"] == "LH_ERR_RANGE" and r["rel_err_f32rec"] == "LH_ERR_RANGE", r
+    # the flag is sticky until read: after the raise the next (healthy) forward is clean again
+    y = _make(sd)(x.to(DEV), e.to(DEV))
+    assert torch.isfinite(y).all()
 
 
 def test_stage_taps_are_bit_reproducible(nets):
