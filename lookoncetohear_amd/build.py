@@ -16,10 +16,17 @@ CSRC = os.path.join(PKG, "csrc")
 SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_recur.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_stream.hip", "lh_comm.hip"]
 LIB = os.path.join(PKG, "_lookonce_hip.so")
 ARCH = "gfx950"
-# per-file flags.  lh_recur.hip: its recurrent steps are hand-ordered (one MFMA, then the vector instructions that fit in its
-# shadow, then a scheduling fence); the SLP vectoriser would gather the scalar fp32 operations of different slots into
-# packed instructions at one place and undo that order.
-FILE_FLAGS = {"lh_recur.hip": ["-fno-slp-vectorize"]}
+# -fno-slp-vectorize for EVERY file: hipcc's SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_add_f32 /
+# v_pk_mul_f32 / v_pk_fma_f32.  (1) Correctness: with those in the LayerNorm statistics of k_proj_ln_res, lanes 48..63 of a
+# wave lose one accumulate step whenever a workgroup of a DIFFERENT, matrix-heavy kernel (the LSTM or attention kernels,
+# launched on a second HIP stream) shares the CU — same binary, bit-exact when it runs alone or next to itself;
+# scripts/race_probe.py reproduces it in 11 of 12 launches, the build without packed fp32 in 0 of 20
+# (profiles/r03c_packed_fp32_corruption.txt).  The same signature (mean / scale error of whole rows, only with co-resident
+# workgroups) was seen in round 1 in k_qkv_proj_ln and worked around there with a full LDS drain.  (2) Performance: packed
+# fp32 is not faster on CDNA4 (one v_pk_fma_f32 issues like two v_fma_f32) and the vectoriser undoes the hand-ordered
+# MFMA / vector interleave of lh_recur.hip.
+NO_SLP = ["-fno-slp-vectorize", "-fno-vectorize"]      # (the loop vectoriser packs fp32 the same way)
+FILE_FLAGS = {}
 
 
 def _newer(dst, srcs):
@@ -39,11 +46,12 @@ def build_hip(force: bool = False, verbose: bool = True, extra_flags=(), out: st
         return out
     objdir = os.path.join(PKG, "build" if out == LIB else "build_" + os.path.basename(out).replace(".so", ""))
     os.makedirs(objdir, exist_ok=True)
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", *extra_flags]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", *NO_SLP, *extra_flags]
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *flags, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        extra_env = os.environ.get("LH_FLAGS_" + src.replace(".hip", "").upper(), "").split()      # bisect hook
+        cmd = [hipcc, *flags, *FILE_FLAGS.get(src, []), *extra_env, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -262,7 +262,9 @@ __device__ __forceinline__ f32x4 e_mma(const _Float16* ahi, const _Float16* alo,
         ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
         ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
     }
-    return am + ac * (1.0f / ESPLIT);
+    // component-wise (a vector expression would lower to packed fp32: build.py)
+    return f32x4{am[0] + ac[0] * (1.0f / ESPLIT), am[1] + ac[1] * (1.0f / ESPLIT), am[2] + ac[2] * (1.0f / ESPLIT),
+                 am[3] + ac[3] * (1.0f / ESPLIT)};
 }
 
 // position row (in the [B][T][65][64] activation) of window element k of (sequence s, step p)
@@ -378,7 +380,8 @@ __global__ void __launch_bounds__(256, 2) k_emb_gx(const _Float16* __restrict__ 
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const f32x4 acc = am[i] + ac[i] * (1.0f / ESPLIT);
+                const f32x4 acc = f32x4{am[i][0] + ac[i][0] * (1.0f / ESPLIT), am[i][1] + ac[i][1] * (1.0f / ESPLIT),
+                                        am[i][2] + ac[i][2] * (1.0f / ESPLIT), am[i][3] + ac[i][3] * (1.0f / ESPLIT)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cs[(m * 16 + g4 * 4 + r) * GX_CSP + (wave * 2 + i) * 16 + l15] = acc[r];
             }
@@ -981,7 +984,9 @@ __global__ void __launch_bounds__(512, 1) k_emb_head(const float* __restrict__ z
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) am[mt][nt] = am[mt][nt] + ac[mt][nt] * (1.0f / ESPLIT);
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) am[mt][nt][r] = am[mt][nt][r] + ac[mt][nt][r] * (1.0f / ESPLIT);
     float mean[4][4], rstd[4][4];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {

@@ -82,6 +82,20 @@ __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h,
     }
 }
 
+// s_waitcnt lgkmcnt(0) tied to the destination registers of a group of LDS reads: nothing that uses them can be scheduled
+// (or counted-waited) ahead of it.  Needed where one of several ds_read_b128 in flight has (nearly) uniform addresses:
+// profiles/r03c_lds_broadcast_overtake.txt.
+template <int NV>
+__device__ __forceinline__ void lds_drain(float4 (&v)[NV]) {
+#if defined(__AMDGCN__)
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
+#else
+    (void)v;
+#endif
+}
+
 // Per-head LayerNorm + split-precision store, one wave per head (N values held flat, index i = f*D + e = the
 // reference's reshape order, in LDS at ysrc[0 .. 8*NOCT); entries >= N are zero; gw / gb are zero-padded to 8*NOCT so
 // pad outputs are exactly 0).  A lane owns octets lane + 64 k; out-of-range slots are clamped to the last octet (the
@@ -306,6 +320,10 @@ extern "C" int lh_probe_qkv_trace_read(unsigned long long* host_dst) {
 namespace lh {
 #endif
 
+#if defined(LH_DBG_K6)
+__device__ unsigned lh_dbg_k6[4];
+__device__ float lh_dbg_part[8 * 24 * 256 * 4];
+#endif
 // ------------------------------------------------------------------------------------------------------
 // attn_concat_proj + LN over (f,c) + residual (+ speaker gain); persistent, grid-stride over frames
 // ------------------------------------------------------------------------------------------------------
@@ -319,6 +337,11 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float ys[NF * YP];
     __shared__ float red[4];
+#if defined(LH_FIX_F2)
+    __shared__ float red2[4];
+#else
+    float* red2 = red;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
     f16x8 wh[2], wl[2];
@@ -373,16 +396,40 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
         for (int k = 0; k < NSLOT; ++k) {
             const int i = min(tid + 256 * k, N4 - 1);
             v[k] = *reinterpret_cast<const float4*>(&ys[(i >> 4) * YP + (i & 15) * 4]);
-            if (tid + 256 * k < N4) s += v[k].x + v[k].y + v[k].z + v[k].w;
         }
+        // all seven reads drained before the first add: the last slot is clamped (lanes 16.. of wave 0 and all other waves
+        // read ONE address), the same shape as HeadLN::read above — see lds_drain()
+#if !defined(LH_FIX_F5)
+        lds_drain(v);
+#endif
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k)
+            if (tid + 256 * k < N4) s += v[k].x + v[k].y + v[k].z + v[k].w;
         const float mean = block_sum_256(s, red) * (1.0f / N);
         float vs = 0.f;
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) {
             const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+#if defined(LH_FIX_F7)
+            vs = __builtin_fmaf(tid + 256 * k < N4 ? 1.0f : 0.0f, dx * dx + dy * dy + dz * dz + dw * dw, vs);
+#elif defined(LH_DBG_K6)
+            if (tid + 256 * k < N4) {
+                vs += dx * dx + dy * dy + dz * dz + dw * dw;
+                if (k == 6) atomicAdd(&lh_dbg_k6[1], 1u);
+            }
+            if (k == 6 && tid == 0) atomicAdd(&lh_dbg_k6[0], 1u);
+            if (k == 6 && tid == 255) atomicAdd(&lh_dbg_k6[2], 1u);
+#else
             if (tid + 256 * k < N4) vs += dx * dx + dy * dy + dz * dz + dw * dw;
+#endif
         }
-        const float rstd = rsqrtf(block_sum_256(vs, red) * (1.0f / N) + LN_EPS);
+#if defined(LH_DBG_K6)
+        if (blockIdx.x < 8 && fidx / (int)gridDim.x < 24) {
+            float* d = lh_dbg_part + ((blockIdx.x * 24 + fidx / (int)gridDim.x) * 256 + tid) * 4;
+            d[0] = vs; d[1] = mean; d[2] = v[6].x; d[3] = s;
+        }
+#endif
+        const float rstd = rsqrtf(block_sum_256(vs, red2) * (1.0f / N) + LN_EPS);
         // residual + normalised value per slot, then (block 0 only) ALL speaker-gain loads of the frame, then the stores:
         // vmcnt counts loads and stores in one order, so a gain load issued behind the previous slot's store is usable only
         // once that store has been acknowledged — interleaved, every slot paid a store round trip
@@ -454,3 +501,14 @@ extern "C" int lh_proj_ln_res(const float* merged, const void* w_pk, const float
                        (const _Float16*)w_pk, bias, slope, ln_w, ln_b, y2, gain, out, T, nframes);
     return check_launch();
 }
+
+#if defined(LH_DBG_K6)
+extern "C" int lh_dbg_part_read(float* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(lh::lh_dbg_part), sizeof(lh::lh_dbg_part)) == hipSuccess ? 0 : 1;
+}
+extern "C" int lh_dbg_k6_read(unsigned* host4, int reset) {
+    if (hipMemcpyFromSymbol(host4, HIP_SYMBOL(lh::lh_dbg_k6), 16) != hipSuccess) return 1;
+    if (reset) { unsigned z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lh::lh_dbg_k6), z, 16); }
+    return 0;
+}
+#endif

@@ -55,7 +55,8 @@ __device__ __forceinline__ f32x4 mma_tile(const _Float16* ahi, const _Float16* a
         ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
         ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
     }
-    return am + ac;
+    // component-wise: a vector add would lower to v_pk_add_f32 (see build.py on packed fp32)
+    return f32x4{am[0] + ac[0], am[1] + ac[1], am[2] + ac[2], am[3] + ac[3]};
 }
 
 // weight image: [n-tile][kstep][lane][hi 8 | lo 8] fp16 (weights.py: pack_linear_f16x3)

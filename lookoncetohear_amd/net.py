@@ -364,6 +364,11 @@ class Net(nn.Module):
             for i in range(self.n_blocks):
                 bp = pk["blocks"][i]
                 bs = state["gridnet_bufs"][f"buf{i}"]
+                if os.environ.get("LOOKONCE_KV_PER_BLOCK") == "1":      # probe: a private q / kx / vx set per block
+                    alt = ws.setdefault("_kv_sets", [None] * self.n_blocks)
+                    if alt[i] is None:
+                        alt[i] = {k: torch.zeros_like(ws[k]) for k in ("q", "kx", "vx")}
+                    ws = dict(ws, **alt[i])
                 h0, c0 = c32(bs["h0"]), c32(bs["c0"])
                 hN, cN = new(h0), new(c0)
                 fuse = mode == 1 and self.fuse_linear
@@ -409,9 +414,17 @@ class Net(nn.Module):
                 lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
                          P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
                          P(ws["kx"]), P(ws["vx"]), None, Bn, T, st)
-                lib.call("lh_local_attn", P(ws["q"]), P(ws["kx"]), P(ws["vx"]), P(xb), Bn, T, st)
+                xm = xb
+                if os.environ.get("LOOKONCE_ATTN_OWN_BUF") == "1":      # probe: attention output in a buffer nothing else touches
+                    if "_xm" not in ws:
+                        self._ws[(Bn, T, str(dev))]["_xm"] = [torch.empty_like(xb) for _ in range(self.n_blocks)]
+                        ws = self._ws[(Bn, T, str(dev))] if "_kv_sets" not in ws else dict(ws, _xm=self._ws[(Bn, T, str(dev))]["_xm"])
+                    xm = ws["_xm"][i]
+                lib.call("lh_local_attn", P(ws["q"]), P(ws["kx"]), P(ws["vx"]), P(xm), Bn, T, st)
+                if taps is not None:
+                    taps[f"blocks.{i}.attn"] = xm.clone()          # head-major [B][T][4][97][16]
                 gain = ws["gain"] if (i == 0 and self.n_blocks > 1) else None   # `batch * embed` before block 1
-                lib.call("lh_proj_ln_res", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
+                lib.call("lh_proj_ln_res", P(xm), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
                          P(bp["proj_ln_w"]), P(bp["proj_ln_b"]), P(xc), P(gain) if gain is not None else None, P(xa),
                          Bn, T, st)
                 if want_state:
@@ -539,8 +552,9 @@ class Streamer:
         self.pos = z(1, dtype=torch.int32)
         self.gain = z(B, F_, C_)
         self.gain_raw = z(B, F_ * C_)
-        # range flag of the split-precision kernels, copied into pinned host memory at the end of every chunk (part of the
-        # captured graph) and looked at when the NEXT chunk arrives — the consumer has synchronised on the output by then
+        # range flag of the split-precision kernels: every RANGE_POLL-th chunk an asynchronous 4-byte copy into pinned host
+        # memory follows the chunk's launches (outside the captured graph: a copy node per chunk cost 26 us of a 0.30 ms
+        # chunk), and the word is looked at when later chunks arrive — so an overflow raises within RANGE_POLL + 1 chunks
         self.range_word = torch.zeros(1, dtype=torch.int32)
         if dev.type == "cuda":
             self.range_word = self.range_word.pin_memory()
@@ -573,6 +587,8 @@ class Streamer:
             self.graph = self.graphs[0]
             self.reset()
 
+    RANGE_POLL = 16          # chunks between polls of the range flag (128 ms of audio)
+
     def _version_stamp(self) -> int:
         if self.net._blob is not None:
             return 0
@@ -585,9 +601,6 @@ class Streamer:
             # ring slot counter, kept in [0, window): an ever-growing int32 would go negative after 2^31 chunks and C's
             # `%` would then index before the ring
             self.pos.add_(1).remainder_(self.net.local_atten_len)
-            if self.net.range_check:
-                st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-                self.net._lib(self.chunk).call("lh_range_flag_copy", self.range_word.data_ptr(), st)
 
     def reset(self):
         for st in self.sets:
@@ -614,15 +627,15 @@ class Streamer:
         if cur is not self._pk:
             raise RuntimeError("the Net's parameters changed after this Streamer was built (its HIP graphs hold pointers "
                                "into the old packed weights): create a new streamer with net.make_streamer(...)")
-        # ... and a parameter updated IN PLACE (optimizer step, load_state_dict) without any other `Net` call in between
-        # would replay silently on the old images: a cheap version stamp (sum of the tensors' version counters) every
-        # 64th chunk catches it within half a second of audio
         if int(self.range_word[0]) != 0:
             self.range_word.zero_()
             st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
             net._lib(self.chunk).call("lh_range_flag_clear", st)
             raise RuntimeError("LH_ERR_RANGE: an earlier chunk produced non-finite samples (fp16 split overflow of the "
                                "residual stream, or inf / NaN in the input); reset() the streamer")
+        # ... and a parameter updated IN PLACE (optimizer step, load_state_dict) without any other `Net` call in between
+        # would replay silently on the old images: a cheap version stamp (sum of the tensors' version counters) every
+        # 64th chunk catches it within half a second of audio
         self._n_steps += 1
         if net._blob is None and (self._n_steps & 63) == 0 and self._version_stamp() != self._stamp:
             raise RuntimeError("a parameter of the Net was modified in place after this Streamer was built: create a new "
@@ -633,5 +646,9 @@ class Streamer:
                 self.graphs[self.parity].replay()
             else:
                 self._body(self.parity)
+            if net.range_check and (self._n_steps % self.RANGE_POLL) == 0:
+                st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+                with _device_of(self.chunk):
+                    net._lib(self.chunk).call("lh_range_flag_copy", self.range_word.data_ptr(), st)
         self.parity ^= 1
         return self.out

@@ -1,0 +1,182 @@
+"""GPU probe (test tooling): stress of ONE C-ABI call under co-residency with foreign kernels.  A quiet run gives the
+reference output; then the call is launched on stream 1 over and over while stream 0 is kept busy with another kernel
+(`--noise intra|qkv|proj|none`), and every output is compared with the reference.
+    python scripts/race_probe.py --call proj --noise intra --reps 40"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lookoncetohear_amd import _cabi, config  # noqa: E402
+from lookoncetohear_amd.net import Net  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--call", default="proj")
+ap.add_argument("--noise", default="intra")
+ap.add_argument("--reps", type=int, default=40)
+ap.add_argument("--batch", type=int, default=16)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+lib = _cabi.load()
+torch.manual_seed(0)
+net = Net(**config.TSH_PARAMS).eval().to(dev)
+pk = net._weights(dev)
+bp = pk["blocks"][1]
+B, T = args.batch, 625
+P = lambda t: t.data_ptr()
+g = torch.Generator().manual_seed(3)
+rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+x1, x2, gain = rnd(B, T, 97, 64), rnd(B, T, 97, 64), rnd(B, 97, 64)
+nx = rnd(32, T, 97, 64)
+nout = torch.empty_like(nx)
+nh0 = torch.zeros(32 * 97, 64, device=dev)
+nhN, ncN = torch.zeros_like(nh0), torch.zeros_like(nh0)
+mm_a, mm_b = rnd(4096, 4096), rnd(4096, 4096)
+mm_c = torch.empty_like(mm_a)
+s0, s1 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+ws = net._workspace(B, T, dev)
+wsn = net._workspace(32, T, dev)
+
+
+def call(out, st):
+    if args.call == "proj":
+        lib.call("lh_proj_ln_res", P(x1), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]), P(bp["proj_ln_w"]),
+                 P(bp["proj_ln_b"]), P(x2), P(gain), P(out), B, T, st)
+    elif args.call == "qkv":
+        lib.call("lh_qkv_proj_ln", P(x1), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]), P(bp["lnq_b"]),
+                 P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]), P(ws["kx"]), P(ws["vx"]), None, B, T, st)
+    else:
+        raise SystemExit("unknown --call")
+
+
+def result(out):
+    if args.call == "proj":
+        return out.clone()
+    return torch.cat([ws["q"].flatten().float(), ws["kx"].flatten().float(), ws["vx"].flatten().float()])
+
+
+def noise(st):
+    if args.noise == "intra":
+        lib.call("lh_intra_block", P(nx), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]), P(bp["intra_lin_b"]), P(nout), 32 * T, st)
+    elif args.noise == "qkv":
+        lib.call("lh_qkv_proj_ln", P(nx), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]), P(bp["lnq_b"]),
+                 P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(wsn["q"]), P(wsn["kx"]), P(wsn["vx"]), None, 32, T, st)
+    elif args.noise == "proj":
+        lib.call("lh_proj_ln_res", P(nx), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]), P(bp["proj_ln_w"]),
+                 P(bp["proj_ln_b"]), P(nx), None, P(nout), 32, T, st)
+    elif args.noise == "copy":
+        nout.copy_(nx)
+    elif args.noise == "inter":
+        lib.call("lh_inter_block", P(nx), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]), P(bp["inter_lin_b"]),
+                 P(nh0), P(nh0), P(nhN), P(ncN), P(nout), 32, T, st)
+    elif args.noise == "attn":
+        lib.call("lh_local_attn", P(wsn["q"]), P(wsn["kx"]), P(wsn["vx"]), P(nout), 32, T, st)
+    elif args.noise == "intra_old":
+        lib.call("lh_set_tuning", 2, 2)
+        lib.call("lh_intra_block", P(nx), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]), P(bp["intra_lin_b"]), P(nout), 32 * T, st)
+        lib.call("lh_set_tuning", 2, 0)
+    elif args.noise == "sincos":          # plain torch elementwise kernels: VALU + transcendental, no LDS, no MFMA
+        torch.sin(nx, out=nout)
+    elif args.noise == "matmul":          # rocBLAS / hipBLASLt GEMM: MFMA + LDS
+        torch.matmul(mm_a, mm_b, out=mm_c)
+
+
+out = torch.empty_like(x1)
+call(out, torch.cuda.current_stream(dev).cuda_stream)
+torch.cuda.synchronize()
+ref = result(out)
+import numpy as np
+import ctypes
+
+
+def parts():
+    try:
+        buf = np.zeros(8 * 24 * 256 * 4, dtype=np.float32)
+        if lib.raw("lh_dbg_part_read")(buf.ctypes.data_as(ctypes.c_void_p)) != 0:
+            return None
+        return buf.reshape(8, 24, 256, 4).copy()
+    except AttributeError:
+        return None
+
+
+ref_parts = parts()
+bad_runs, bad_vals = 0, 0
+for rep in range(args.reps):
+    with torch.cuda.stream(s0):
+        if args.noise != "none":
+            for _ in range(3):
+                noise(s0.cuda_stream)
+    with torch.cuda.stream(s1):
+        call(out, s1.cuda_stream)
+    torch.cuda.synchronize()
+    r = result(out)
+    nb = int((r != ref).sum())
+    if nb and ref_parts is not None and rep < 3:
+        pp = parts()
+        for name, j in (("vs partial", 0), ("mean", 1), ("v[6].x", 2), ("s partial", 3)):
+            dd = pp[..., j] != ref_parts[..., j]
+            if dd.any():
+                w, f, t = np.nonzero(dd)
+                if j == 0:       # which slot's contribution is missing?  (thread tid owns float4 i = tid + 256 k of the frame)
+                    sdd = net.state_dict()
+                    pre_ = "tfgridnet.blocks.1.attn_concat_proj."
+                    W_, b_, a_ = sdd[pre_ + "0.weight"].double().reshape(64, 64), sdd[pre_ + "0.bias"].double(), sdd[pre_ + "1.weight"].double()
+                    for q_ in range(min(4, len(w))):
+                        fidx = int(w[q_]) + 512 * int(f[q_])
+                        bb, tt = fidx // T, fidx % T
+                        m_ = x1[bb, tt].reshape(4, 97, 16).permute(1, 0, 2).reshape(97, 64).double()
+                        z_ = m_ @ W_.t() + b_
+                        z_ = torch.where(z_ >= 0, z_, a_ * z_).flatten()
+                        mean_ = float(ref_parts[w[q_], f[q_], t[q_], 1])
+                        slots = [float(((z_[4 * (int(t[q_]) + 256 * k_):4 * (int(t[q_]) + 256 * k_) + 4] - mean_) ** 2).sum()) if int(t[q_]) + 256 * k_ < 1552 else 0.0 for k_ in range(7)]
+                        print(f"      wg {w[q_]} frame {f[q_]} thread {t[q_]}: quiet {ref_parts[w[q_], f[q_], t[q_], 0]:.5f} noisy {pp[w[q_], f[q_], t[q_], 0]:.5f} deficit "
+                              f"{ref_parts[w[q_], f[q_], t[q_], 0] - pp[w[q_], f[q_], t[q_], 0]:.5f}; per-slot contributions {[round(v_, 5) for v_ in slots]}")
+                print(f"   rep {rep}: {name}: {dd.sum()} (wg, frame, thread) entries differ; threads {sorted(set(t.tolist()))[:24]}; "
+                      f"e.g. wg {w[0]} frame {f[0]} thread {t[0]}: quiet {ref_parts[w[0], f[0], t[0], j]:.6g} noisy {pp[w[0], f[0], t[0], j]:.6g}")
+    bad_runs += nb > 0
+    bad_vals += nb
+try:
+    import ctypes
+    cnt = (ctypes.c_uint * 4)()
+    if lib.raw("lh_dbg_k6_read")(cnt, 0) == 0:
+        print("debug counters: frames seen by thread 0:", cnt[0], " by thread 255:", cnt[2], " lanes through the k = 6 block:", cnt[1],
+              " expected", 16 * cnt[0])
+except AttributeError:
+    pass
+print(f"{os.path.basename(lib.path)} call {args.call} under noise {args.noise}: {bad_runs} of {args.reps} runs differ from the quiet run"
+      f" ({bad_vals} values in total)", flush=True)
+
+# ---- anatomy of a wrong frame (--call proj): is it the LayerNorm statistics (u / w linear in the true pre-LN value z) or z itself?
+if args.call == "proj" and bad_runs:
+    sd = net.state_dict()
+    pre = "tfgridnet.blocks.1.attn_concat_proj."
+    W, bvec, slope = sd[pre + "0.weight"].double().reshape(64, 64), sd[pre + "0.bias"].double(), sd[pre + "1.weight"].double()
+    lw, lb = sd[pre + "3.norm.weight"].double().reshape(97, 64), sd[pre + "3.norm.bias"].double().reshape(97, 64)
+    # keep launching until a bad output is at hand
+    for _ in range(20):
+        with torch.cuda.stream(s0):
+            for _ in range(3):
+                noise(s0.cuda_stream)
+        with torch.cuda.stream(s1):
+            call(out, s1.cuda_stream)
+        torch.cuda.synchronize()
+        if (out != ref).any():
+            break
+    o, r = out.reshape(B, T, 97, 64), ref.reshape(B, T, 97, 64)
+    badf = (o != r).any(-1).any(-1).nonzero()
+    print("bad frames in this run:", len(badf), "first", badf[:5].tolist())
+    for b_, t_ in badf[:3].tolist():
+        m = x1[b_, t_].reshape(4, 97, 16).permute(1, 0, 2).reshape(97, 64).double()       # head-major slab -> [f][c]
+        z = m @ W.t() + bvec
+        z = torch.where(z >= 0, z, slope * z)
+        u_bad = (o[b_, t_].double() / gain[b_].double() - x2[b_, t_].double() - lb) / lw
+        u_ref = (r[b_, t_].double() / gain[b_].double() - x2[b_, t_].double() - lb) / lw
+        for name, u in (("quiet", u_ref), ("noisy", u_bad)):
+            A = torch.stack([z.flatten(), torch.ones(97 * 64, dtype=torch.float64, device=dev)], 1)
+            sol = torch.linalg.lstsq(A, u.flatten()[:, None]).solution.flatten()
+            res = (A @ sol - u.flatten()).abs()
+            print(f"   frame ({b_},{t_}) {name}: u = {sol[0]:.6f} z + {sol[1]:.6f}; max residual {res.max():.3e}; residual > 1e-3 in "
+                  f"{int((res > 1e-3).sum())} values, rows {sorted(set((res.reshape(97, 64) > 1e-3).any(-1).nonzero().flatten().tolist()))[:12]}"
+                  f" cols {sorted(set((res.reshape(97, 64) > 1e-3).any(0).nonzero().flatten().tolist()))[:20]}")

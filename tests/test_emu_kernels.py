@@ -278,9 +278,10 @@ def test_range_contract_raises_instead_of_returning_nan(emu_net):
     y = emu_net(d["mixture"], d["embedding_gt"])
     assert torch.isfinite(y).all()
     st = emu_net.make_streamer(1, "cpu", use_graph=False)
+    st.RANGE_POLL = 2                                     # (16 on the product path: 128 ms of audio)
     st.set_embedding(d["embedding_gt"][:, 0])
     st.step(d["mixture"][:, :, :192])
-    st.step(big[:, :, :192])                              # produces NaN; noticed when the next chunk arrives
+    st.step(big[:, :, :192])                              # produces NaN; polled after this chunk, noticed at the next one
     with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
         st.step(d["mixture"][:, :, :192])
     st.reset()
