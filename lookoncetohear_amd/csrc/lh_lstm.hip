@@ -1106,7 +1106,7 @@ extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* 
     if (h0 == hN || c0 == cN) return LH_ERR_ARG;
     // sequence s = b*97 + f; step p = frame t; row(s,p) = (b*T + p)*97 + f
     const int nseq = B * NF;
-    const int mt = g_tune[1] ? g_tune[1] : (nseq >= 32768 ? 2 : 1);
+    const int mt = g_tune[1] == 2 ? 2 : 1;      // 32-sequence tiles only on request (lh_set_tuning(1, 2): A/B runs, tests/test_emu_kernels.py)
     if (mode == LH_GEMM_F16X3) {
         if (mt == 2)
             return launch_lstm_h3<2>(x, ln_w, ln_b, w_pk, b_sum, h0, c0, hN, cN, h_out, nseq, T, 1, NF, T * NF, 1, NF, H,

@@ -364,11 +364,6 @@ class Net(nn.Module):
             for i in range(self.n_blocks):
                 bp = pk["blocks"][i]
                 bs = state["gridnet_bufs"][f"buf{i}"]
-                if os.environ.get("LOOKONCE_KV_PER_BLOCK") == "1":      # probe: a private q / kx / vx set per block
-                    alt = ws.setdefault("_kv_sets", [None] * self.n_blocks)
-                    if alt[i] is None:
-                        alt[i] = {k: torch.zeros_like(ws[k]) for k in ("q", "kx", "vx")}
-                    ws = dict(ws, **alt[i])
                 h0, c0 = c32(bs["h0"]), c32(bs["c0"])
                 hN, cN = new(h0), new(c0)
                 fuse = mode == 1 and self.fuse_linear
@@ -414,17 +409,11 @@ class Net(nn.Module):
                 lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
                          P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
                          P(ws["kx"]), P(ws["vx"]), None, Bn, T, st)
-                xm = xb
-                if os.environ.get("LOOKONCE_ATTN_OWN_BUF") == "1":      # probe: attention output in a buffer nothing else touches
-                    if "_xm" not in ws:
-                        self._ws[(Bn, T, str(dev))]["_xm"] = [torch.empty_like(xb) for _ in range(self.n_blocks)]
-                        ws = self._ws[(Bn, T, str(dev))] if "_kv_sets" not in ws else dict(ws, _xm=self._ws[(Bn, T, str(dev))]["_xm"])
-                    xm = ws["_xm"][i]
-                lib.call("lh_local_attn", P(ws["q"]), P(ws["kx"]), P(ws["vx"]), P(xm), Bn, T, st)
+                lib.call("lh_local_attn", P(ws["q"]), P(ws["kx"]), P(ws["vx"]), P(xb), Bn, T, st)
                 if taps is not None:
-                    taps[f"blocks.{i}.attn"] = xm.clone()          # head-major [B][T][4][97][16]
+                    taps[f"blocks.{i}.attn"] = xb.clone()          # head-major [B][T][4][97][16]
                 gain = ws["gain"] if (i == 0 and self.n_blocks > 1) else None   # `batch * embed` before block 1
-                lib.call("lh_proj_ln_res", P(xm), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
+                lib.call("lh_proj_ln_res", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
                          P(bp["proj_ln_w"]), P(bp["proj_ln_b"]), P(xc), P(gain) if gain is not None else None, P(xa),
                          Bn, T, st)
                 if want_state:

@@ -132,6 +132,30 @@ def test_pipelined_inter_kernel(emu_net, oracle_cfg_sd):
         assert fm[k].shape == fo[k].shape and (fm[k] - fo[k]).abs().max() < TOL, k
 
 
+def test_unfused_inter_path_with_32_sequence_tiles(emu_net, oracle_cfg_sd):
+    """The unfused inter pass (lh_ln_lstm_inter + lh_linear_res, LOOKONCE_FUSE=0) in its 32-sequence-tile form
+    (k_ln_lstm_h3<2>, only selected with lh_set_tuning(1, 2)): B=2, T=5 = 194 sequences = 6 tiles + a ragged one, carried
+    (h0, c0) in and out against the oracle."""
+    cfg, sd = oracle_cfg_sd
+    lib = emu_net._lib_override
+    B, T = 2, 5
+    d = synth.batch([30, 31], 128 * T + 64)
+    st = O.random_state(cfg, B, 17)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    saved = emu_net.fuse_linear
+    emu_net.fuse_linear = False
+    lib.call("lh_set_tuning", 1, 2)
+    try:
+        y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    finally:
+        emu_net.fuse_linear = saved
+        lib.call("lh_set_tuning", 1, 0)
+    assert (y - yo).abs().max() < TOL
+    fo, fm = O.flat_state(so), O.flat_state(s2)
+    for k in fo:
+        assert (fm[k] - fo[k]).abs().max() < TOL, k
+
+
 def test_tiled_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     """The mid-size intra path (lh_ln_lstm_intra: 16-sequence MFMA tiles + lh_linear_res, used between 128 and 8192
     frames) forced at a size where `Net` would pick the streaming mat-vec kernel."""

@@ -188,6 +188,40 @@ def test_stage_taps_are_bit_reproducible(nets):
         assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[1][k], runs[2][k]), k
 
 
+def test_two_forwards_on_two_streams_are_bit_identical(oracle_cfg_sd):
+    """Two `Net` instances, two HIP streams, both forwards in flight together: each must equal the same forward run alone,
+    bit for bit.  Guards the packed-fp32 corruption of profiles/r03c_packed_fp32_corruption.txt (kernels built with the
+    vectorisers lost an accumulate step in lanes 48..63 whenever a workgroup of the LSTM / attention kernels of the OTHER
+    stream shared their CU: 1e-2 errors in 11 of 12 launches) — the library is built without packed fp32 now."""
+    _, sd = oracle_cfg_sd
+    nets2 = [_make(sd), _make(sd)]
+    for n in nets2:
+        n.range_check = False                      # no host wait inside the forward: both streams must be fed back to back
+    d = synth.batch(list(range(60, 68)), 80000)
+    mix = d["mixture"].repeat(4, 1, 1).to(DEV)
+    emb = d["embedding_gt"].repeat(4, 1, 1).to(DEV)
+    halves = [(mix[:16].contiguous(), emb[:16].contiguous()), (mix[16:].contiguous(), emb[16:].contiguous())]
+    alone = [nets2[i](*halves[i]) for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    for rep in range(4):
+        cur = torch.cuda.current_stream(DEV)
+        for s_ in streams:
+            s_.wait_stream(cur)
+        outs = []
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                for _ in range(2):                 # keep both queues busy for the whole of the other's forward
+                    y = nets2[i](*halves[i])
+                outs.append(y)
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            assert torch.equal(outs[i], alone[i]), (rep, i, float((outs[i] - alone[i]).abs().max()))
+    for n in nets2:
+        n._ws.clear()
+    torch.cuda.empty_cache()
+
+
 def test_packed_blob_drives_the_c_abi_without_net(oracle_cfg_sd):
     """the packed weight blob (checkpoint.export_packed / import_packed, include/lookonce_weights.h)
     is enough to run the separator through the C ABI — no `Net` instance: tensors of the blob are uploaded as they
