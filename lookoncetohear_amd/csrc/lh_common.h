@@ -113,36 +113,18 @@ __device__ __forceinline__ float group16_sum(float v) {
 
 __device__ __forceinline__ float wave_sum(float v) {
     v = group16_sum(v);
-#if defined(LH_FIX_F3)      // probe: cross-row step without the LDS crossbar (ds_bpermute): v_readlane of the four row totals
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return (r0 + r1) + (r2 + r3);
-#else
     v += __shfl_xor(v, 16);
     return v + __shfl_xor(v, 32);
-#endif
 }
 
 // Sum `v` over all threads of a 256-thread workgroup; `red` is a >= 4-float LDS scratch.
 // Contains two barriers; every thread must call it.
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
-#if defined(LH_FIX_F6) && defined(__AMDGCN__)
-    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(v));
-#endif
     v = wave_sum(v);
-#if defined(LH_FIX_F4)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
     __syncthreads();                       // protect `red` from the previous use
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    const float t = red[0] + red[1] + red[2] + red[3];
-#if defined(LH_FIX_F1)
-    __syncthreads();
-#endif
-    return t;
+    return red[0] + red[1] + red[2] + red[3];
 }
 
 // "The value of v is decided HERE": an empty volatile asm that claims to rewrite the registers.  Arithmetic on a global

@@ -82,20 +82,6 @@ __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h,
     }
 }
 
-// s_waitcnt lgkmcnt(0) tied to the destination registers of a group of LDS reads: nothing that uses them can be scheduled
-// (or counted-waited) ahead of it.  Needed where one of several ds_read_b128 in flight has (nearly) uniform addresses:
-// profiles/r03c_lds_broadcast_overtake.txt.
-template <int NV>
-__device__ __forceinline__ void lds_drain(float4 (&v)[NV]) {
-#if defined(__AMDGCN__)
-#pragma unroll
-    for (int k = 0; k < NV; ++k)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
-#else
-    (void)v;
-#endif
-}
-
 // Per-head LayerNorm + split-precision store, one wave per head (N values held flat, index i = f*D + e = the
 // reference's reshape order, in LDS at ysrc[0 .. 8*NOCT); entries >= N are zero; gw / gb are zero-padded to 8*NOCT so
 // pad outputs are exactly 0).  A lane owns octets lane + 64 k; out-of-range slots are clamped to the last octet (the
@@ -114,10 +100,10 @@ struct HeadLN {
 
     // LDS -> registers; returns the lane's partial sum.  `zero8` = 8 floats of zeros in LDS (16-byte aligned): slots past
     // the row read those instead, so nothing has to be masked out of the sum.
-    // All reads are drained (lgkmcnt(0)) before the first add.  With hipcc's own counted waits (lgkmcnt(3), (1), ...
-    // between the eight ds_read_b128 of a V row, most lanes of the last slot reading one shared address) about 0.3 %
-    // of the rows came out with a wrong mean on the MI355X — some adds consumed a register before its read had
-    // landed — whenever two workgroups shared a CU; run-to-run different, never on Q / K (scripts/gpu_determinism.py).
+    // (Rounds 1-2 drained all reads with an inline s_waitcnt lgkmcnt(0) here: ~0.3 % of the V rows had come out with a wrong
+    // mean whenever two workgroups shared a CU, read as an LDS return-order problem.  It was the packed-fp32 accumulation
+    // chain the vectoriser built from these adds — profiles/r03c_packed_fp32_corruption.txt; the library is compiled
+    // without packed fp32 now and the drain is gone: QKV 1.08 -> 1.03 ms per step.)
     __device__ __forceinline__ float read(const float* ysrc, const float* zero8, int lane) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -129,13 +115,8 @@ struct HeadLN {
         }
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-#if defined(__AMDGCN__)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[k][0]), "+v"(x[k][1]), "+v"(x[k][2]), "+v"(x[k][3]), "+v"(x[k][4]),
-                         "+v"(x[k][5]), "+v"(x[k][6]), "+v"(x[k][7]));
-#endif
+        for (int k = 0; k < NS; ++k)
             s += (x[k][0] + x[k][1]) + (x[k][2] + x[k][3]) + (x[k][4] + x[k][5]) + (x[k][6] + x[k][7]);
-        }
         return s;
     }
     __device__ __forceinline__ void load_affine(const float* __restrict__ gw, const float* __restrict__ gb, int lane) {
@@ -337,11 +318,6 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float ys[NF * YP];
     __shared__ float red[4];
-#if defined(LH_FIX_F2)
-    __shared__ float red2[4];
-#else
-    float* red2 = red;
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
     f16x8 wh[2], wl[2];
@@ -397,11 +373,6 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
             const int i = min(tid + 256 * k, N4 - 1);
             v[k] = *reinterpret_cast<const float4*>(&ys[(i >> 4) * YP + (i & 15) * 4]);
         }
-        // all seven reads drained before the first add: the last slot is clamped (lanes 16.. of wave 0 and all other waves
-        // read ONE address), the same shape as HeadLN::read above — see lds_drain()
-#if !defined(LH_FIX_F5)
-        lds_drain(v);
-#endif
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k)
             if (tid + 256 * k < N4) s += v[k].x + v[k].y + v[k].z + v[k].w;
@@ -410,9 +381,7 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) {
             const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
-#if defined(LH_FIX_F7)
-            vs = __builtin_fmaf(tid + 256 * k < N4 ? 1.0f : 0.0f, dx * dx + dy * dy + dz * dz + dw * dw, vs);
-#elif defined(LH_DBG_K6)
+#if defined(LH_DBG_K6)            // anatomy probe of profiles/r03c_packed_fp32_corruption.txt (scripts/race_probe.py)
             if (tid + 256 * k < N4) {
                 vs += dx * dx + dy * dy + dz * dz + dw * dw;
                 if (k == 6) atomicAdd(&lh_dbg_k6[1], 1u);
@@ -429,7 +398,7 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
             d[0] = vs; d[1] = mean; d[2] = v[6].x; d[3] = s;
         }
 #endif
-        const float rstd = rsqrtf(block_sum_256(vs, red2) * (1.0f / N) + LN_EPS);
+        const float rstd = rsqrtf(block_sum_256(vs, red) * (1.0f / N) + LN_EPS);
         // residual + normalised value per slot, then (block 0 only) ALL speaker-gain loads of the frame, then the stores:
         // vmcnt counts loads and stores in one order, so a gain load issued behind the previous slot's store is usable only
         // once that store has been acknowledged — interleaved, every slot paid a store round trip
