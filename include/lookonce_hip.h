@@ -56,9 +56,9 @@ int lh_selftest_fp16_subnormal(lh_stream_t stream);
  *   LH_GEMM_F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32); w_pk = fp32 image  [dirs][4][4][32][64]
  *   LH_GEMM_F16X3 split precision: each fp32 operand = fp16 hi + fp16 lo, three fp16 MFMAs
  *                 (hi*hi, hi*lo, lo*hi) accumulated in fp32 (~22 mantissa bits).  Every split-precision image and
- *                 row of the SEPARATOR entry points stores lo = fp16(v - hi), NOT rescaled (fp16 subnormals go
- *                 through the matrix core at full value; since ABI 9 — before, only the recurrent kernels did);
- *                 the embedder entry points (lh_emb_*) keep lo = fp16((v - hi) * 2^11);
+ *                 row of every entry point stores lo = fp16(v - hi), NOT rescaled (fp16 subnormals go through the
+ *                 matrix core at full value, lh_selftest_fp16_subnormal checks it): the recurrent kernels since ABI 6,
+ *                 the other separator kernels since ABI 9, the embedder entry points (lh_emb_*) since ABI 10;
  *                 w_pk = fp16 image [dirs][4 waves][4 gates][4 ksteps][64 lanes][hi 8 | lo 8] (lo unscaled) of
  *                 [W_ih * ln_w | W_hh] and b_sum = b_ih + b_hh + W_ih ln_b, rows of both scaled by the exponent factor of their gate (-log2 e for i, f, o;
  *                 -2 log2 e for g: weights.py gate_prescale). The LayerNorm affine is folded into

@@ -20,7 +20,10 @@ constexpr int EKS = 4;            // emb_ks (unfold / ConvTranspose1d kernel)
 constexpr int EE = 8;             // ceil(512 / 65)
 constexpr int EDQK = EF * EE;     // 520
 constexpr int EDV = EF * VD;      // 1040
-constexpr float ESPLIT = 2048.0f;
+// Split form of the embedder kernels: v = hi + lo * (1 / ESPLIT).  ESPLIT = 1 is the separator's un-rescaled form (lh_split.h:
+// the matrix core takes fp16 subnormals at full value); rounds 1-2 used 2048 here.  The multiplications by ESPLIT and
+// 1 / ESPLIT below fold away at compile time.
+constexpr float ESPLIT = 1.0f;
 
 // ---------------------------------------------------------------------------------------------------------------
 // 1 / std(x[b]) over all samples of all microphones, unbiased (torch.std default) — tfgridnet_orig/tfgridnet.py:109

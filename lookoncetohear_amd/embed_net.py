@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _cabi
-from .weights import pack_linear_f16x3, pack_mfma_f32, split_f16
+from .weights import pack_linear_sep as pack_linear_f16x3, pack_mfma_f32, split_f16_unscaled as split_f16      # un-rescaled split (lh_embed.hip ESPLIT = 1)
 
 
 class _LN4D(nn.Module):
