@@ -361,20 +361,33 @@ extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float
 }
 
 // ---- range contract of the split-precision arithmetic (include/lookonce_hip.h)
+static unsigned* range_flag_addr() {          // device address of the flag on the CURRENT device (symbol lookup once per device)
+    static unsigned* addr[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!addr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lh::lh_range_flag)) != hipSuccess) return nullptr;
+        addr[dev] = static_cast<unsigned*>(p);
+    }
+    return addr[dev];
+}
 extern "C" int lh_range_flag_copy(void* host_pinned, lh_stream_t stream) {
     if (!host_pinned) return LH_ERR_ARG;
-    return hipMemcpyFromSymbolAsync(host_pinned, HIP_SYMBOL(lh::lh_range_flag), sizeof(unsigned), 0, hipMemcpyDeviceToHost,
-                                    (hipStream_t)stream) == hipSuccess ? LH_OK : LH_ERR_LAUNCH;
+    unsigned* p = range_flag_addr();
+    if (!p) return LH_ERR_LAUNCH;
+    return hipMemcpyAsync(host_pinned, p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess
+               ? LH_OK : LH_ERR_LAUNCH;
 }
 extern "C" int lh_range_flag_clear(lh_stream_t stream) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(lh::lh_range_flag)) != hipSuccess) return LH_ERR_LAUNCH;
+    unsigned* p = range_flag_addr();
+    if (!p) return LH_ERR_LAUNCH;
     return hipMemsetAsync(p, 0, sizeof(unsigned), (hipStream_t)stream) == hipSuccess ? LH_OK : LH_ERR_LAUNCH;
 }
 extern "C" int lh_range_status(lh_stream_t stream) {
     unsigned v = 0;
-    if (hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(lh::lh_range_flag), sizeof(unsigned), 0, hipMemcpyDeviceToHost,
-                                 (hipStream_t)stream) != hipSuccess)
+    unsigned* p = range_flag_addr();
+    if (!p || hipMemcpyAsync(&v, p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
         return LH_ERR_LAUNCH;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return LH_ERR_LAUNCH;
     if (!v) return LH_OK;
