@@ -158,12 +158,6 @@ class Net(nn.Module):
         # With `range_check` every forward ends with lh_range_status (one 4-byte copy + a wait on the launch stream) and
         # raises instead of returning inf / NaN; a `Streamer` polls the same flag one chunk late.
         self.range_check = os.environ.get("LOOKONCE_RANGE_CHECK", "1") != "0"
-        # Small offline forwards (zero state in, no state out, B*T below `graph_max_frames`) are launch-bound: 27 kernels of
-        # ~1.5 ms in total at batch 1, and the range check at the end makes the host wait.  Their launch sequence is captured
-        # once per (shape, device, weights) in a HIP graph and replayed (LOOKONCE_GRAPH=0 switches it off).
-        self.graph_small = os.environ.get("LOOKONCE_GRAPH", "1") != "0"
-        self.graph_max_frames = 8192
-        self._graphs: Dict[tuple, dict] = {}
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
         self.fuse_intra_min_frames = 8192
@@ -306,42 +300,7 @@ class Net(nn.Module):
             self._zeros[key] = self.init_buffers(B, device)        # read-only: the kernels write state to separate tensors
         return self._zeros[key]
 
-    def _graphed(self, x: torch.Tensor, embed: torch.Tensor) -> torch.Tensor:
-        """Offline forward from the zero state through a cached HIP graph (small batches: launch-bound).  The graph owns
-        static input / output tensors, a private workspace and a reference to the packed weights it points into; it is
-        rebuilt when the weights were re-packed."""
-        dev = x.device
-        with torch.no_grad(), _device_of(x):
-            pk = self._weights(dev)
-            key = (tuple(x.shape), tuple(embed.shape), str(dev), self.gemm_mode, self.fuse_linear)
-            ent = self._graphs.get(key)
-            if ent is None or ent["pk"] is not pk:
-                if len(self._graphs) > 3:
-                    self._graphs.clear()
-                sx = x.detach().float().contiguous().clone()
-                se = embed.detach().float().contiguous().clone()
-                cur = torch.cuda.current_stream(dev)
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):                # warm-up outside the capture: allocates workspace / zero state
-                    self._separate(sx, se, None, False, _raw=True)
-                cur.wait_stream(side)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    y, _ = self._separate(sx, se, None, False, _raw=True)
-                T = (sx.shape[-1] - self.nfft) // self.stft_chunk_size + 1
-                ws = self._ws.pop((sx.shape[0], T, str(dev)), None)     # private to the graph from now on
-                ent = dict(g=g, sx=sx, se=se, y=y, pk=pk, ws=ws)
-                self._graphs[key] = ent
-            ent["sx"].copy_(x)
-            ent["se"].copy_(embed)
-            ent["g"].replay()
-            out = ent["y"].clone()
-            if self.range_check:
-                self._raise_on_range(self._lib(x), torch.cuda.current_stream(dev).cuda_stream)
-        return out
-
-    def _separate(self, x: torch.Tensor, embed: torch.Tensor, state: Optional[dict], want_state: bool = True, _raw: bool = False):
+    def _separate(self, x: torch.Tensor, embed: torch.Tensor, state: Optional[dict], want_state: bool = True):
         """TFGridNet.forward (reference tfgridnet_causal.py:188-283) on the HIP kernels."""
         if self.training and torch.is_grad_enabled():
             raise RuntimeError("lookoncetohear_amd.Net is an inference-only drop-in (forward kernels, no autograd): call "
@@ -352,10 +311,6 @@ class Net(nn.Module):
         assert x.dim() == 3 and x.shape[1] == self.num_ch, "input must be [B, num_ch, N]"
         Bn, _, n = x.shape
         from_zero = state is None and not want_state
-        if (from_zero and not _raw and self.graph_small and x.is_cuda and self._debug_taps is None and self._prof is None
-                and n >= nfft and Bn * ((n - nfft) // hop + 1) < self.graph_max_frames
-                and not torch.cuda.is_current_stream_capturing()):
-            return self._graphed(x, embed), None
         if state is None:
             state = self._zero_state(Bn, dev) if from_zero else self.init_buffers(Bn, dev)
         T = (n - nfft) // hop + 1
@@ -480,7 +435,7 @@ class Net(nn.Module):
                      P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), Bn, T, st)
             if want_state:
                 state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
-            if self.range_check and not _raw:
+            if self.range_check:
                 self._raise_on_range(lib_, st)
         return y, (state if want_state else None)
 
