@@ -50,19 +50,19 @@ bench)              # the default bench line, as the driver runs it
     cut -c1-3000 gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
 profile)            # rocprofv3 kernel stats + PMC passes (separate runs) of the B=32 bench; then the bench line itself
     cd /tmp && export TMPDIR=/tmp
-    P="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
+    P="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-power"
     timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o r1 -- $P > $R/gpurun_out/prof_stats.log 2>&1; echo "rocprof rc=$?"
     python $R/scripts/rocpd_summary.py /tmp/prof_stats/r1_results.db $R/gpurun_out/kernel_stats.csv
     for C in FETCH_SIZE WRITE_SIZE; do
         timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$C -o r1 -- $P > $R/gpurun_out/prof_$C.log 2>&1; echo "rocprof $C rc=$?"
         python $R/scripts/rocpd_summary.py /tmp/prof_$C/r1_results.db $R/gpurun_out/pmc_$C.csv --pmc
     done
-    python $R/scripts/make_pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv 32 $R/gpurun_out/pmc_traffic.json
-    [ "${LITE:-0}" = "1" ] && { cd $R; head -12 gpurun_out/kernel_stats.csv; exit 0; }      # LITE=1: stats + traffic passes only
+    [ "${LITE:-0}" = "1" ] && { python $R/scripts/make_pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv 32 $R/gpurun_out/pmc_traffic.json; cd $R; head -12 gpurun_out/kernel_stats.csv; exit 0; }      # LITE=1: stats + traffic passes only
     timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_sq -o r1 -- $P > $R/gpurun_out/prof_sq.log 2>&1; echo "rocprof sq rc=$?"
     python $R/scripts/rocpd_summary.py /tmp/prof_sq/r1_results.db $R/gpurun_out/pmc_sq.csv --pmc
     timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM -d /tmp/prof_sq2 -o r1 -- $P > $R/gpurun_out/prof_sq2.log 2>&1; echo "rocprof sq2 rc=$?"
     python $R/scripts/rocpd_summary.py /tmp/prof_sq2/r1_results.db $R/gpurun_out/pmc_sq2.csv --pmc
+    python $R/scripts/make_pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv 32 $R/gpurun_out/pmc_traffic.json $R/gpurun_out/pmc_sq.csv $R/gpurun_out/pmc_sq2.csv
     cd $R
     head -40 gpurun_out/kernel_stats.csv; head -60 gpurun_out/pmc_traffic.json ;;
 *)  echo "unknown task $task"; exit 2 ;;

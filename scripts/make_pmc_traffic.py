@@ -1,6 +1,10 @@
 """profiles/pmc_traffic.json from the two PMC passes (FETCH_SIZE, WRITE_SIZE) summarised by scripts/rocpd_summary.py.
 
-    python scripts/make_pmc_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <batch> <out.json>
+    python scripts/make_pmc_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <batch> <out.json> [<pmc_sq.csv> <pmc_sq2.csv>]
+
+With the two SQ passes (scripts/gpu.sh profile) every kernel also gets `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES /
+(GRBM_GUI_ACTIVE x 1024 SIMDs), `valu_busy` = 4 x SQ_ACTIVE_INST_VALU / the same (the SQ_ACTIVE_* counters tick in
+quad-cycles) and the raw counters; LOOKONCE_COMMIT in the environment stamps the file with the commit it was measured on.
 
 Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950
 FETCH_SIZE tallies 128-byte requests as 64 bytes, so it is doubled; WRITE_SIZE is used as is.  Values are averages per
@@ -21,16 +25,31 @@ def load(path):
     return out
 
 
-def main(fetch_csv, write_csv, batch, out_json):
+def load_counters(path):
+    """kernel, grid, counter, dispatches, avg -> {(kernel, grid): {counter: avg per dispatch}}"""
+    out = {}
+    for row in csv.reader(open(path)):
+        if len(row) == 5 and row[0] != "kernel" and not row[0].startswith("#"):
+            out.setdefault((row[0], int(row[1])), {})[row[2]] = float(row[4])
+    return out
+
+
+def main(fetch_csv, write_csv, batch, out_json, sq_csv=None, sq2_csv=None):
+    import os
     B = int(batch)
     fe, wr = load(fetch_csv), load(write_csv)
+    sq = {}
+    for path in (sq_csv, sq2_csv):
+        if path and os.path.exists(path):
+            for k, v in load_counters(path).items():
+                sq.setdefault(k, {}).update(v)
     A = 15.52e6 * B
     qk = 5.82e6 * B
     wg = lambda nseq: ((nseq + 15) // 16) * 256          # LSTM launches: 16 sequences per 256-thread workgroup
     # C-ABI call -> (kernel-name substring, grid size or None, algorithmic bytes per kernel launch)
     table = {
-        "lh_intra_block": (("k_ln_lstm_lin", "k_lstm_pp"), None, 2.5 * A),
-        "lh_inter_block": ("k_lstm_lin8", None, 2.0 * A),
+        "lh_intra_block": (("k_intra_xp", "k_ln_lstm_lin"), None, 2.5 * A),
+        "lh_inter_block": (("k_lstm_lin8", "k_inter_xp"), None, 2.0 * A),
         "lh_qkv_proj_ln": ("k_qkv_proj_ln", None, 2 * A + 2 * qk),
         "lh_local_attn": ("k_local_attn", None, 2 * qk + 2 * A),
         "lh_proj_ln_res": ("k_proj_ln_res", None, 3 * A),
@@ -55,10 +74,18 @@ def main(fetch_csv, write_csv, batch, out_json):
             "algorithmic_bytes_per_launch": alg,
         }
         kernels[call]["ratio_to_algorithmic"] = kernels[call]["hbm_bytes_per_launch"] / alg
+        c = sq.get(f[0][0])
+        if c and c.get("GRBM_GUI_ACTIVE"):
+            simd_cycles = c["GRBM_GUI_ACTIVE"] * 1024.0
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                kernels[call]["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+            if "SQ_ACTIVE_INST_VALU" in c:
+                kernels[call]["valu_busy"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles
+            kernels[call]["sq_counters_per_launch"] = c
     json.dump({
         "source": f"{fetch_csv} + {write_csv} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                   "summarised by scripts/rocpd_summary.py --pmc)",
-        "batch_per_gpu": B,
+        "batch_per_gpu": B, "commit": os.environ.get("LOOKONCE_COMMIT", "unknown"),
         "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM "
                        "section); WRITE_SIZE uncorrected",
         "kernels": kernels}, open(out_json, "w"), indent=1)
@@ -68,4 +95,4 @@ def main(fetch_csv, write_csv, batch, out_json):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:7])
