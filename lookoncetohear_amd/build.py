@@ -26,7 +26,12 @@ ARCH = "gfx950"
 # fp32 is not faster on CDNA4 (one v_pk_fma_f32 issues like two v_fma_f32) and the vectoriser undoes the hand-ordered
 # MFMA / vector interleave of lh_recur.hip.
 NO_SLP = ["-fno-slp-vectorize", "-fno-vectorize"]      # (the loop vectoriser packs fp32 the same way)
-FILE_FLAGS = {}
+# Exception: the direct-form FIR / FFT kernels of the rendering row (not on the separator path) are pure
+# fp32 vector arithmetic and run at HALF the rate without v_pk_fma_f32 (0.47 -> 0.93 ms for 256-tap responses); their packed
+# chains are plain accumulations without exec-masked side blocks and came through the same stress bit-exact (0 of 120
+# launches next to the LSTM / attention kernels, scripts/race_probe.py --call render256|render4096;
+# tests/test_render.py::test_render_next_to_lstm_kernels_is_bit_identical keeps checking it).
+FILE_FLAGS = {"lh_render.hip": ["-fslp-vectorize", "-fvectorize"]}
 
 
 def _newer(dst, srcs):

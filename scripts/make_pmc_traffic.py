@@ -3,7 +3,7 @@
     python scripts/make_pmc_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <batch> <out.json> [<pmc_sq.csv> <pmc_sq2.csv>]
 
 With the two SQ passes (scripts/gpu.sh profile) every kernel also gets `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES /
-(GRBM_GUI_ACTIVE x 1024 SIMDs), `valu_busy` = 4 x SQ_ACTIVE_INST_VALU / the same (the SQ_ACTIVE_* counters tick in
+(GRBM_GUI_ACTIVE / 8 XCCs x 1024 SIMDs), `valu_busy` = 4 x SQ_ACTIVE_INST_VALU / the same (the SQ_ACTIVE_* counters tick in
 quad-cycles) and the raw counters; LOOKONCE_COMMIT in the environment stamps the file with the commit it was measured on.
 
 Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950
@@ -76,7 +76,8 @@ def main(fetch_csv, write_csv, batch, out_json, sq_csv=None, sq2_csv=None):
         kernels[call]["ratio_to_algorithmic"] = kernels[call]["hbm_bytes_per_launch"] / alg
         c = sq.get(f[0][0])
         if c and c.get("GRBM_GUI_ACTIVE"):
-            simd_cycles = c["GRBM_GUI_ACTIVE"] * 1024.0
+            # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCCs (6.4e6 for a 0.41 ms launch at ~1.9 GHz); 1024 SIMDs per chip
+            simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
                 kernels[call]["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
             if "SQ_ACTIVE_INST_VALU" in c:

@@ -36,6 +36,13 @@ nhN, ncN = torch.zeros_like(nh0), torch.zeros_like(nh0)
 mm_a, mm_b = rnd(4096, 4096), rnd(4096, 4096)
 mm_c = torch.empty_like(mm_a)
 s0, s1 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+from lookoncetohear_amd.render import BinauralRenderer  # noqa: E402
+renderer = BinauralRenderer()
+r_src = rnd(16, 4, 80000) * 0.1
+r_rir = {"render256": rnd(16, 4, 2, 256) * 0.05, "render4096": rnd(16, 4, 2, 4096) * 0.02}
+r_gain = torch.ones(16, 4, device=dev)
+r_tgt = torch.zeros(16, dtype=torch.int32, device=dev)
+ren_out = [None]
 ws = net._workspace(B, T, dev)
 wsn = net._workspace(32, T, dev)
 
@@ -47,6 +54,9 @@ def call(out, st):
     elif args.call == "qkv":
         lib.call("lh_qkv_proj_ln", P(x1), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]), P(bp["lnq_b"]),
                  P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]), P(ws["kx"]), P(ws["vx"]), None, B, T, st)
+    elif args.call in ("render256", "render4096"):
+        with torch.cuda.stream(s1 if st == s1.cuda_stream else torch.cuda.current_stream(dev)):
+            ren_out[:] = [renderer.render(r_src, r_rir[args.call], r_gain, r_tgt)]
     else:
         raise SystemExit("unknown --call")
 
@@ -54,6 +64,8 @@ def call(out, st):
 def result(out):
     if args.call == "proj":
         return out.clone()
+    if args.call.startswith("render"):
+        return torch.cat([t.flatten().float() for t in ren_out[0]])
     return torch.cat([ws["q"].flatten().float(), ws["kx"].flatten().float(), ws["vx"].flatten().float()])
 
 

@@ -85,3 +85,38 @@ def test_gpu_render_full_size():
     assert torch.equal(ev[:3], a[3][0, :3])
     with pytest.raises(RuntimeError):
         rr.render(srcs, rirs, gains, tgt)                       # CPU tensors: no fallback
+
+
+@pytest.mark.gpu
+def test_render_next_to_lstm_kernels_is_bit_identical():
+    """lh_render.hip is the one file still built with packed fp32 (v_pk_fma_f32: the FIR / FFT kernels run at half the rate
+    without it).  Packed chains of OTHER kernels lost accumulate steps in lanes 48..63 whenever a workgroup of the LSTM
+    kernels (second HIP stream) shared their CU — profiles/r03c_packed_fp32_corruption.txt; the render kernels came through
+    that stress bit-exact, and this test keeps it that way: renders on one stream while the fused intra LSTM kernel runs
+    back to back on another must equal the quiet render, both response lengths (direct form and FFT path)."""
+    from lookoncetohear_amd import config
+    from lookoncetohear_amd.net import Net
+    lib = _cabi.load()
+    dev = torch.device("cuda:0")
+    rr = BinauralRenderer()
+    torch.manual_seed(0)
+    net = Net(**config.TSH_PARAMS).eval().to(dev)
+    bp = net._weights(dev)["blocks"][0]
+    nx = torch.randn(32, 625, 97, 64, device=dev)
+    nout = torch.empty_like(nx)
+    P = lambda t: t.data_ptr()
+    s0, s1 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for taps, seeds in ((256, [0, 1, 2, 3]), (4096, [4, 5, 6, 7])):
+        sc, srcs, rirs, gains, tgt = _batch(seeds, 80000, taps)
+        args = (srcs.to(dev), rirs.to(dev), gains.to(dev), tgt.to(dev))
+        quiet = rr.render(*args)
+        torch.cuda.synchronize()
+        for rep in range(8):
+            with torch.cuda.stream(s0):
+                for _ in range(3):
+                    lib.call("lh_intra_block", P(nx), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
+                             P(bp["intra_lin_b"]), P(nout), 32 * 625, s0.cuda_stream)
+            with torch.cuda.stream(s1):
+                noisy = rr.render(*args)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(quiet, noisy)), (taps, rep)
