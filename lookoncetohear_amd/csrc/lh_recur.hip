@@ -10,10 +10,15 @@
 //   phase C (off the chain): lin(h_{t-1}) (6 MFMAs), gx' = LN(x_{t+1}) W_ih'^T (24 MFMAs, the NON-recurrent half of step
 //                            t+1's gates, one step ahead)          30 MFMAs  ||  the cell update of step t (40 transcendentals)
 //
-// and the instruction order inside each phase is given to the scheduler explicitly (sched_group_barrier: one MFMA, then
-// the vector instructions that fit in its shadow) instead of "12 MFMAs, then a slab of vector work".  The measured issue
-// model (profiles/r02a_ubench_issue_model.txt) is: a 16x16x32 MFMA holds the matrix pipe 19 cycles but the wave's issue
-// only ~7.5, two plain vector instructions (or one transcendental) behind it are free.
+// and the instruction order inside each phase is written down: a "zipper" (xp_zip) issues one MFMA, then its slice of a
+// list of small vector operations, then a scheduling fence.  (sched_group_barrier patterns did not produce the interleave
+// on this code — the MFMAs stayed in runs of 8..24 — and the fenced zipper only survives without the SLP vectoriser, which
+// otherwise gathers the scalar fp32 operations of different slots into packed instructions at one place: build.py.)
+// The measured issue model (profiles/r02a_ubench_issue_model.txt): a 16x16x32 MFMA holds the matrix pipe 19 cycles but
+// the wave's issue only ~7.5; two plain vector instructions (or one transcendental) behind it are free.  Result
+// (profiles/r03a_*): a wave-step 2886 -> 2088 cycles alone on the CU, 4212 -> ~2690 with a second workgroup — and the
+// shader clock 1929 -> 1788 MHz at the same 1.38 kW package power: the call gains 6 %.  The path is power-bound
+// (DESIGN.md section 5).
 //
 // Further instruction diet against k_ln_lstm_lin: the gate bias leaves the accumulator initialisation (16 v_mov per
 // step) and enters the cell update as a factor, 1 + 2^(a + b) = fma(2^a, 2^b, 1) with 2^b held per lane; the cell state
