@@ -160,10 +160,11 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const float p = sv[u] * inv;           // exactly 0 outside the band
-                const _Float16 h = (_Float16)p;
+                _Float16 h, l;
+                split_hl(p, h, l);
                 if (TQ == 16 * MQ || ir < TQ) {
                     ph[ir][sub + 16 * u] = h;
-                    pl[ir][sub + 16 * u] = (_Float16)(p - (float)h);
+                    pl[ir][sub + 16 * u] = l;
                 }
             }
         }
@@ -275,9 +276,10 @@ __global__ void __launch_bounds__(256) k_ring_pack(const float* __restrict__ kbu
             for (int e = 0; e < 8; ++e) {
                 const int f = blk * 8 + e;
                 const float v = f < DQK ? kbuf[row * DQK + f] : 0.f;
-                const _Float16 h = (_Float16)v;
+                _Float16 h, l;
+                split_hl(v, h, l);
                 h8[e] = h;
-                l8[e] = (_Float16)(v - (float)h);
+                l8[e] = l;
             }
             _Float16* d = kx + (bh * tkp + r) * LDQKH + blk * 16;
             *reinterpret_cast<f16x8*>(d) = h8;
@@ -292,9 +294,10 @@ __global__ void __launch_bounds__(256) k_ring_pack(const float* __restrict__ kbu
             f16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const _Float16 h = (_Float16)v[e];
+                _Float16 h, l;
+                split_hl(v[e], h, l);
                 o[e] = h;
-                o[4 + e] = (_Float16)(v[e] - (float)h);
+                o[4 + e] = l;
             }
             *reinterpret_cast<f16x8*>(vx + (bh * tkp + r) * LDVH + qd * 8) = o;
         }

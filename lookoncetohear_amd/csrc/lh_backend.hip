@@ -104,10 +104,11 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
 
         // one spectrum value -> row jd of source s's A image
         auto put_sx = [&](int jd, int s, int k, float v) {
-            const _Float16 h = (_Float16)v;
+            _Float16 h, l;
+            split_hl(v, h, l);
             const int idx = s * BE_SA + a_index<BE_NJ>(jd, k);
             sxh[idx] = h;
-            sxl[idx] = (_Float16)(v - (float)h);
+            sxl[idx] = l;
         };
         // Sx frame 0: the carried spectrum of the previous call (first tile of the clip), the previous tile's last
         // frame (inside a run), or recomputed from the halo frames (first tile of a later run)

@@ -127,6 +127,21 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// Split v = hi + lo (hi = fp16(v), lo = fp16(v - hi)): an error-free transformation — it only works if `hi` is ONE number.
+// hipcc folds fptrunc(fmul a, b) into v_fma_mixlo_f16 (the EXACT product rounded once to fp16) whatever -ffp-contract says,
+// and it does so per use: handed `x * rstd`, it computed the `hi` it subtracts from the fused form and the `hi` it stores
+// from the rounded fp32 product.  In the rare double-rounding cases the two differ by one fp16 ulp and hi + lo is off by
+// 2^-11 |v| — seen as 6e-5 errors of whole LSTM outputs against 3e-7 (round 3; which pattern the compiler picks changes
+// with every flag, the SLP build of rounds 1-2 happened to be consistent).  The empty asm makes the operand opaque: the
+// product is rounded to fp32 once and both conversions start from that register.
+__device__ __forceinline__ void split_hl(float v, _Float16& hi, _Float16& lo) {
+#if defined(__AMDGCN__)
+    asm("" : "+v"(v));
+#endif
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
 // "The value of v is decided HERE": an empty volatile asm that claims to rewrite the registers.  Arithmetic on a global
 // load's result cannot be hoisted above it — used at the top of an unrolled recurrent step so the consumer of a load
 // issued one step earlier (and its s_waitcnt vmcnt) stays behind the step barrier instead of landing right after the load.

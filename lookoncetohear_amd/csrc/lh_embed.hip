@@ -20,9 +20,9 @@ constexpr int EKS = 4;            // emb_ks (unfold / ConvTranspose1d kernel)
 constexpr int EE = 8;             // ceil(512 / 65)
 constexpr int EDQK = EF * EE;     // 520
 constexpr int EDV = EF * VD;      // 1040
-// Split form of the embedder kernels: v = hi + lo * (1 / ESPLIT).  ESPLIT = 1 is the separator's un-rescaled form (lh_split.h:
-// the matrix core takes fp16 subnormals at full value); rounds 1-2 used 2048 here.  The multiplications by ESPLIT and
-// 1 / ESPLIT below fold away at compile time.
+// Split form of the embedder kernels: the separator's un-rescaled v = hi + lo (split_hl, lh_common.h; the matrix core takes
+// fp16 subnormals at full value); rounds 1-2 stored lo * 2048 here.  ESPLIT = 1 remains in the accumulator recombinations
+// (am + ac / ESPLIT), where it folds away at compile time.
 constexpr float ESPLIT = 1.0f;
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -243,9 +243,10 @@ __device__ __forceinline__ void e_store_split4(_Float16* ahi, _Float16* alo, int
     f16x4 h4, l4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const _Float16 h = (_Float16)x[i];
+        _Float16 h, l;
+        split_hl(x[i], h, l);
         h4[i] = h;
-        l4[i] = (_Float16)((x[i] - (float)h) * ESPLIT);
+        l4[i] = l;
     }
     const int idx = e_index<RP>(row, k0);
     *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
@@ -293,9 +294,10 @@ __global__ void __launch_bounds__(256) k_emb_lnsplit(const float* __restrict__ x
         f16x4 h4, l4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const _Float16 h = (_Float16)v[i];
+            _Float16 h, l;
+            split_hl(v[i], h, l);
             h4[i] = h;
-            l4[i] = (_Float16)((v[i] - (float)h) * ESPLIT);
+            l4[i] = l;
         }
         *reinterpret_cast<f16x4*>(&xh[r * C + q * 4]) = h4;
         *reinterpret_cast<f16x4*>(&xl[r * C + q * 4]) = l4;
@@ -471,9 +473,10 @@ __global__ void __launch_bounds__(256, 2) k_emb_lstm(const float* __restrict__ g
             lstm_cell(am[0][r] + ac[0][r] * INV, am[1][r] + ac[1][r] * INV, am[2][r] + ac[2][r] * INV,
                       am[3][r] + ac[3][r] * INV, creg[r], hv);
             const int row = g4 * 4 + r;
-            const _Float16 th = (_Float16)hv;
+            _Float16 th, tl;
+            split_hl(hv, th, tl);
             ahi[(nxt * 16 + row) * EL_AP + unit] = th;
-            alo[(nxt * 16 + row) * EL_AP + unit] = (_Float16)((hv - (float)th) * ESPLIT);
+            alo[(nxt * 16 + row) * EL_AP + unit] = tl;
             hf[(nxt * 16 + row) * EL_HP + unit] = hv;
         }
         __syncthreads();
@@ -622,9 +625,10 @@ __device__ __forceinline__ void e_ln_head_split(const float* ys, int yp, int col
         const int i = lane + 64 * k;
         if (i < EQP) {
             const float o = i < N ? (at(k) - mean) * rstd * gw[i] + gb[i] : 0.f;
-            const _Float16 h = (_Float16)o;
+            _Float16 h, l;
+            split_hl(o, h, l);
             dh[i] = h;
-            dl[i] = (_Float16)((o - (float)h) * ESPLIT);
+            dl[i] = l;
         }
     }
 }
@@ -787,9 +791,10 @@ __global__ void __launch_bounds__(256) k_emb_vt(const float* __restrict__ v, _Fl
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float x = tl[t4 + j][cc];
-                const _Float16 h = (_Float16)x;
+                _Float16 h, l;
+                split_hl(x, h, l);
                 h4[j] = h;
-                l4[j] = (_Float16)((x - (float)h) * ESPLIT);
+                l4[j] = l;
             }
             const long o = (long)(c0 + cc) * Tp + t0 + t4;
             *reinterpret_cast<f16x4*>(&oh[o]) = h4;
@@ -912,9 +917,10 @@ __global__ void __launch_bounds__(256) k_emb_softmax(const float* __restrict__ s
     _Float16* pl = ph + img;
     for (int i = lane; i < Tp; i += 64) {
         const float x = i < T ? __expf(sr[i] - mx) * inv : 0.f;
-        const _Float16 h = (_Float16)x;
+        _Float16 h, l;
+        split_hl(x, h, l);
         ph[i] = h;
-        pl[i] = (_Float16)((x - (float)h) * ESPLIT);
+        pl[i] = l;
     }
 }
 

@@ -79,9 +79,10 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
                 f16x4 h4, l4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const _Float16 h = (_Float16)v[q];
+                    _Float16 h, l;
+                    split_hl(v[q], h, l);
                     h4[q] = h;
-                    l4[q] = (_Float16)(v[q] - (float)h);
+                    l4[q] = l;
                 }
                 const int idx = (m * FE_NJ + j) * FE_AP + c4 * 4;
                 *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
@@ -123,9 +124,10 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
                         float v = am[i][r] + ac[i][r];
                         if (t < 0) v = cbuf_in[(((long)b * 4 + ch) * 2 + (t + 2)) * NF + f];   // carried halo frames
                         if (t >= T) v = 0.0f;
-                        const _Float16 h = (_Float16)v;
+                        _Float16 h, l;
+                        split_hl(v, h, l);
                         sth[(f + 1) * FE_SP + j * 4 + ch] = h;
-                        stl[(f + 1) * FE_SP + j * 4 + ch] = (_Float16)(v - (float)h);
+                        stl[(f + 1) * FE_SP + j * 4 + ch] = l;
                         // new halo state = the last two frames of the halo-extended spectrum (exact fp32)
                         if (t >= T - 2 && t < T) cbuf_out[(((long)b * 4 + ch) * 2 + (t - (T - 2))) * NF + f] = v;
                     }

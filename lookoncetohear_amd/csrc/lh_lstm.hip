@@ -209,10 +209,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int LH_AP = 144;      // fp16 elements per LDS row: 128 + 16 pad (288 B: conflict-free ds_read_b128)
 constexpr int LH_HP = 68;       // fp32 copy of h: 64 + 4 pad
 
-__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
-}
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) { split_hl(v, hi, lo); }
 
 template <int MT>
 __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__ x, const float* __restrict__ lnw,

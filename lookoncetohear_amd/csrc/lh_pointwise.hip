@@ -153,9 +153,10 @@ struct HeadLN {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float y = x[k][e] * rstd * wv[e] + bv[e];
-                const _Float16 h = (_Float16)y;
+                _Float16 h, l;
+                split_hl(y, h, l);
                 h8[e] = h;
-                l8[e] = (_Float16)(y - (float)h);
+                l8[e] = l;
             }
             f16x8 o0 = h8, o1 = l8;
             if (VLAYOUT) {

@@ -167,9 +167,10 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
         const float v[4] = {a, b, c, d};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const _Float16 th = (_Float16)v[i];
+            _Float16 th, tl;
+            split_hl(v[i], th, tl);
             h4[i] = th;
-            l4[i] = (_Float16)(v[i] - (float)th);
+            l4[i] = tl;
         }
         *reinterpret_cast<xp_f16x4*>(&ahi[idx]) = h4;
         *reinterpret_cast<xp_f16x4*>(&alo[idx]) = l4;
@@ -273,9 +274,9 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
 #endif
             [&] { y.x = v.x * rstd; y.y = v.y * rstd; },
             [&] { y.z = v.z * rstd; y.w = v.w * rstd; },
-            [&] { h4[0] = (_Float16)y.x; h4[1] = (_Float16)y.y; h4[2] = (_Float16)y.z; h4[3] = (_Float16)y.w; },
-            [&] { l4[0] = (_Float16)(y.x - (float)h4[0]); l4[1] = (_Float16)(y.y - (float)h4[1]); },
-            [&] { l4[2] = (_Float16)(y.z - (float)h4[2]); l4[3] = (_Float16)(y.w - (float)h4[3]); },
+            [&] { _Float16 a_, b_; split_hl(y.x, a_, b_); h4[0] = a_; l4[0] = b_; },
+            [&] { _Float16 a_, b_; split_hl(y.y, a_, b_); h4[1] = a_; l4[1] = b_; },
+            [&] { _Float16 a_, b_, c_, d_; split_hl(y.z, a_, b_); split_hl(y.w, c_, d_); h4[2] = a_; l4[2] = b_; h4[3] = c_; l4[3] = d_; },
             [&] {
                 *reinterpret_cast<xp_f16x4*>(&ahi[cur * NS * XP_AP + a_row]) = h4;
                 *reinterpret_cast<xp_f16x4*>(&alo[cur * NS * XP_AP + a_row]) = l4;
@@ -324,8 +325,8 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
         auto cI = [&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const float hv = acc[3][r] * __builtin_fmaf(2.0f, tc[r], -1.0f);
-            const _Float16 th = (_Float16)hv;
-            const _Float16 tl = (_Float16)(hv - (float)th);
+            _Float16 th, tl;
+            split_hl(hv, th, tl);
             ahi[(nxt * NS + r) * XP_AP + a_cell] = th;
             alo[(nxt * NS + r) * XP_AP + a_cell] = tl;
         };
@@ -493,9 +494,10 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
         const float v[4] = {a, b, c, d};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const _Float16 th = (_Float16)v[i];
+            _Float16 th, tl;
+            split_hl(v[i], th, tl);
             h4[i] = th;
-            l4[i] = (_Float16)(v[i] - (float)th);
+            l4[i] = tl;
         }
         *reinterpret_cast<xp_f16x4*>(&ahi[idx]) = h4;
         *reinterpret_cast<xp_f16x4*>(&alo[idx]) = l4;
@@ -606,9 +608,9 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
                 [&] { carry = load_row(xb, it + 3); },
                 [&] { y.x = v.x * rstd; y.y = v.y * rstd; },
                 [&] { y.z = v.z * rstd; y.w = v.w * rstd; },
-                [&] { h4[0] = (_Float16)y.x; h4[1] = (_Float16)y.y; h4[2] = (_Float16)y.z; h4[3] = (_Float16)y.w; },
-                [&] { l4[0] = (_Float16)(y.x - (float)h4[0]); l4[1] = (_Float16)(y.y - (float)h4[1]); },
-                [&] { l4[2] = (_Float16)(y.z - (float)h4[2]); l4[3] = (_Float16)(y.w - (float)h4[3]); },
+                [&] { _Float16 a_, b_; split_hl(y.x, a_, b_); h4[0] = a_; l4[0] = b_; },
+                [&] { _Float16 a_, b_; split_hl(y.y, a_, b_); h4[1] = a_; l4[1] = b_; },
+                [&] { _Float16 a_, b_, c_, d_; split_hl(y.z, a_, b_); split_hl(y.w, c_, d_); h4[2] = a_; l4[2] = b_; h4[3] = c_; l4[3] = d_; },
                 [&] {
                     *reinterpret_cast<xp_f16x4*>(&ahi[cur * NS * XP_AP + a_row]) = h4;
                     *reinterpret_cast<xp_f16x4*>(&alo[cur * NS * XP_AP + a_row]) = l4;
@@ -655,8 +657,8 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
         auto cI = [&](auto m_) {
             constexpr int m = decltype(m_)::value;
             hreg[m] = acc[m][3] * __builtin_fmaf(2.0f, tc[m], -1.0f);
-            const _Float16 th = (_Float16)hreg[m];
-            const _Float16 tl = (_Float16)(hreg[m] - (float)th);
+            _Float16 th, tl;
+            split_hl(hreg[m], th, tl);
             ahi[nxt * NS * XP_AP + a_cell + 4 * m] = th;
             alo[nxt * NS * XP_AP + a_cell + 4 * m] = tl;
         };

@@ -30,9 +30,10 @@ __device__ __forceinline__ void store_split4(_Float16* ahi, _Float16* alo, int r
     f16x4 h4, l4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const _Float16 h = (_Float16)x[i];
+        _Float16 h, l;
+        split_hl(x[i], h, l);
         h4[i] = h;
-        l4[i] = (_Float16)(x[i] - (float)h);
+        l4[i] = l;
     }
     const int idx = a_index<RP>(row, k0);
     *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;

@@ -223,10 +223,11 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
                 float hv;
                 lstm_cell(gate, gf, gg, go, c, hv);
                 hs[hb ^ 1][unit] = hv;
-                const _Float16 hh = (_Float16)hv;
+                _Float16 hh, hl_;
+                split_hl(hv, hh, hl_);
                 const int idx = a_index<IM_TC>(it, unit);
                 hhi[idx] = hh;
-                hlo[idx] = (_Float16)(hv - (float)hh);
+                hlo[idx] = hl_;
             }
             hb ^= 1;
             __syncthreads();
