@@ -543,7 +543,8 @@ class Streamer:
         self.gain_raw = z(B, F_ * C_)
         # range flag of the split-precision kernels: every RANGE_POLL-th chunk an asynchronous 4-byte copy into pinned host
         # memory follows the chunk's launches (outside the captured graph: a copy node per chunk cost 26 us of a 0.30 ms
-        # chunk), and the word is looked at when later chunks arrive — so an overflow raises within RANGE_POLL + 1 chunks
+        # chunk, the separate copy ~0.15 ms of the one chunk it follows), and the word is looked at when later chunks
+        # arrive — so an overflow raises within RANGE_POLL + 1 chunks
         self.range_word = torch.zeros(1, dtype=torch.int32)
         if dev.type == "cuda":
             self.range_word = self.range_word.pin_memory()
@@ -576,7 +577,7 @@ class Streamer:
             self.graph = self.graphs[0]
             self.reset()
 
-    RANGE_POLL = 16          # chunks between polls of the range flag (128 ms of audio)
+    RANGE_POLL = 64          # chunks between polls of the range flag (0.5 s of audio; a polled chunk costs ~0.15 ms more)
 
     def _version_stamp(self) -> int:
         if self.net._blob is not None:

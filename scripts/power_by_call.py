@@ -39,6 +39,9 @@ class Rec:
         self.calls.append((name, args))
         self.lib.call(name, *args)
 
+    def raw(self, name):
+        return self.lib.raw(name)
+
 
 rec = Rec(lib)
 net._lib_override = rec
