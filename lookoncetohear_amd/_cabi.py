@@ -93,6 +93,22 @@ def device_of(t):
 
 
 _hip_lib = None
+_selftested = set()
+
+
+def selftest_device(lib: "Lib", device_index: int) -> None:
+    """Once per process and device: the un-rescaled split relies on the matrix core taking fp16 SUBNORMAL operands at full
+    value (lh_selftest_fp16_subnormal).  A build / mode that flushes them would silently lose the lo halves of every value
+    below 2^-3 — refuse to run instead."""
+    if device_index in _selftested:
+        return
+    import torch
+    with torch.cuda.device(device_index):
+        rc = lib.raw("lh_selftest_fp16_subnormal")(torch.cuda.current_stream(device_index).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"lh_selftest_fp16_subnormal failed on cuda:{device_index} ({ERRORS.get(rc, rc)}): fp16 subnormal "
+                           "MFMA operands are flushed; the split-precision kernels would lose precision silently")
+    _selftested.add(device_index)
 
 
 def load() -> Lib:

@@ -86,7 +86,9 @@ class EmbedTFGridNet(nn.Module):
             return self._lib_override
         if not t.is_cuda:
             raise RuntimeError("lookoncetohear_amd.EmbedTFGridNet runs on an MI355X (ROCm device tensors); there is no CPU path")
-        return _cabi.load()
+        lib = _cabi.load()
+        _cabi.selftest_device(lib, t.device.index if t.device.index is not None else torch.cuda.current_device())
+        return lib
 
     def _weights(self, device) -> dict:
         tensors = list(self.parameters())

@@ -230,7 +230,9 @@ class Net(nn.Module):
         if not t.is_cuda:
             raise RuntimeError("lookoncetohear_amd.Net runs on an MI355X (ROCm device tensors); there is no CPU "
                                "path. Move the module and its inputs to cuda.")
-        return _cabi.load()
+        lib = _cabi.load()
+        _cabi.selftest_device(lib, t.device.index if t.device.index is not None else torch.cuda.current_device())
+        return lib
 
     @classmethod
     def from_packed(cls, path: str, device) -> "Net":
