@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_recur.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_stream.hip", "lh_comm.hip"]
+SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_recur.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_render_fft.hip", "lh_stream.hip", "lh_comm.hip"]
 LIB = os.path.join(PKG, "_lookonce_hip.so")
 ARCH = "gfx950"
 # -fno-slp-vectorize for EVERY file: hipcc's SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_add_f32 /
@@ -26,12 +26,47 @@ ARCH = "gfx950"
 # fp32 is not faster on CDNA4 (one v_pk_fma_f32 issues like two v_fma_f32) and the vectoriser undoes the hand-ordered
 # MFMA / vector interleave of lh_recur.hip.
 NO_SLP = ["-fno-slp-vectorize", "-fno-vectorize"]      # (the loop vectoriser packs fp32 the same way)
-# Exception: the direct-form FIR / FFT kernels of the rendering row (not on the separator path) are pure
-# fp32 vector arithmetic and run at HALF the rate without v_pk_fma_f32 (0.47 -> 0.93 ms for 256-tap responses); their packed
-# chains are plain accumulations without exec-masked side blocks and came through the same stress bit-exact (0 of 120
-# launches next to the LSTM / attention kernels, scripts/race_probe.py --call render256|render4096;
-# tests/test_render.py::test_render_next_to_lstm_kernels_is_bit_identical keeps checking it).
+# The exact hardware condition, isolated to ONE instruction (scripts/ubench/pk_race*.{hip,py}, profiles/r03c): a packed fp32
+# operation (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) whose op_sel crosses the halves of src1 ONLY — op_sel:[0,1],
+# op_sel:[0,1,0] — returns, in lanes 48..63, the result with src1's low-half operand missing (the add returns src0.lo)
+# whenever a wave of a matrix-heavy kernel shares the SIMD; default selects, op_sel:[1,0], [1,1], [1,0,0], [0,0,1], the
+# neg modifiers and op_sel_hi alone are fine; 8 wait states around every instruction change nothing.
+# Exception to NO_SLP: lh_render.hip (direct-form FIR + mixing, SURVEY 8f rank 3, not on the separator path) is pure fp32
+# vector arithmetic and runs at HALF the rate without v_pk_fma_f32 (0.47 -> 0.93 ms for 256-tap responses); its packed
+# instructions use default selects only.  The FFT kernel (complex multiplies -> crossed selects) is its own file,
+# lh_render_fft.hip, built like the rest.  `check_isa` below fails the build if the unsafe form appears anywhere.
 FILE_FLAGS = {"lh_render.hip": ["-fslp-vectorize", "-fvectorize"]}
+
+
+def unsafe_packed_fp32(lib_path: str):
+    """Disassembles the gfx950 code object inside `lib_path` and returns the packed-fp32 instructions whose op_sel crosses
+    the halves of src1 only (see above)."""
+    import re
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as td:
+        # newer llvm-objdump finds the fat-binary section itself
+        out = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--offloading", lib_path], capture_output=True, text=True)
+        text = out.stdout
+        if "v_mfma" not in text:                        # older llvm-objdump: extract the code object by hand
+            raw = open(lib_path, "rb").read()
+            i = raw.find(b"\x7fELF", 1)
+            hits = []
+            while i > 0:
+                hits.append(i)
+                i = raw.find(b"\x7fELF", i + 1)
+            text = ""
+            for k, off in enumerate(hits):
+                co = os.path.join(td, f"co{k}.o")
+                open(co, "wb").write(raw[off:])
+                r = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True)
+                if "v_mfma" in r.stdout or "v_pk_" in r.stdout:
+                    text += r.stdout
+    bad = []
+    for line in text.splitlines():
+        if re.search(r"v_pk_(add|mul|fma)_f32", line) and re.search(r"op_sel:\[0,1(,0)?\]", line):
+            bad.append(line.strip())
+    return bad, text.count("v_pk_fma_f32") + text.count("v_pk_add_f32") + text.count("v_pk_mul_f32"), ("v_mfma" in text)
 
 
 def _newer(dst, srcs):
@@ -68,6 +103,14 @@ def build_hip(force: bool = False, verbose: bool = True, extra_flags=(), out: st
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    bad, n_packed, seen = unsafe_packed_fp32(out)
+    if not seen:
+        raise RuntimeError(f"{out}: could not disassemble the gfx950 code object (ISA guard of build.py)")
+    if bad:
+        raise RuntimeError(f"{out}: {len(bad)} packed-fp32 instructions with src1-crossed op_sel (unsafe on gfx950 next to "
+                           f"matrix-heavy kernels, see build.py), e.g. {bad[0]}")
+    if verbose:
+        print(f"ISA guard: {n_packed} packed fp32 instructions, none with src1-crossed op_sel", flush=True)
     return out
 
 

@@ -95,99 +95,13 @@ __global__ void __launch_bounds__(256) k_fir_causal(const float* __restrict__ x,
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Overlap-save FFT convolution for room-length responses (1024 <= Lh <= 4097): 8192-point complex FFTs in LDS.
-//   * both ears in ONE transform pair: x is real, so  ifft( fft(x) . fft(h_L + i h_R) ) = y_L + i y_R ;
-//   * the forward transform is decimation-in-frequency (natural in, bit-reversed out), the inverse decimation-in-time
-//     (bit-reversed in, natural out) and the spectra are multiplied in bit-reversed order: no reordering pass at all;
-//   * a workgroup owns one row (source) and a group of consecutive 4096-sample output blocks: the response's spectrum
-//     is computed once, kept in 64 VGPRs per thread (the 32 bins the thread multiplies), and reused for every block;
-//   * twiddles exp(-2 pi i k / 8192) are tabulated in LDS once per workgroup (sincospi, ~1 ulp).
-// 20 blocks x 2 transforms x 13 x 4096 butterflies per row against 80000 x 4096 x 2 multiply-adds for the direct form
-// (~1/16 of the FLOPs); the arithmetic is fp32 with the usual O(eps log F) error, inside the same tolerance.
-// ------------------------------------------------------------------------------------------------------
+// The overlap-save FFT path (responses of 1024..4097 taps) lives in lh_render_fft.hip: its complex arithmetic turns into
+// packed fp32 with crossed operand selects under the vectorisers, the instruction form that is unsafe on this chip
+// (build.py), so that file is compiled without them while this one keeps v_pk_fma_f32 for the direct-form FIR.
 constexpr int FC_LOG = 13, FC_F = 1 << FC_LOG;    // transform size
 constexpr int FC_L = FC_F / 2;                    // outputs per block (Lh - 1 <= FC_F - FC_L)
-constexpr int FC_PER = FC_F / 256;                // points per thread
 constexpr int FC_LH_MIN = 1024, FC_LH_MAX = FC_F - FC_L + 1;
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a conj(b)
-
-// forward, decimation in frequency: natural order in, bit-reversed order out.  Ends with a barrier.
-__device__ __forceinline__ void fft_dif(float2* d, const float2* tw, int tid) {
-    for (int lg = FC_LOG; lg >= 1; --lg) {
-        const int half = 1 << (lg - 1), ts = FC_LOG - lg;        // twiddle index = j << ts
-        for (int k = tid; k < FC_F / 2; k += 256) {
-            const int j = k & (half - 1), a = ((k >> (lg - 1)) << lg) + j, b = a + half;
-            const float2 u = d[a], v = d[b];
-            d[a] = make_float2(u.x + v.x, u.y + v.y);
-            d[b] = cmul(make_float2(u.x - v.x, u.y - v.y), tw[j << ts]);
-        }
-        __syncthreads();
-    }
-}
-// inverse (unscaled), decimation in time: bit-reversed order in, natural order out.  Ends with a barrier.
-__device__ __forceinline__ void ifft_dit(float2* d, const float2* tw, int tid) {
-    for (int lg = 1; lg <= FC_LOG; ++lg) {
-        const int half = 1 << (lg - 1), ts = FC_LOG - lg;
-        for (int k = tid; k < FC_F / 2; k += 256) {
-            const int j = k & (half - 1), a = ((k >> (lg - 1)) << lg) + j, b = a + half;
-            const float2 u = d[a], v = cmulc(d[b], tw[j << ts]);
-            d[a] = make_float2(u.x + v.x, u.y + v.y);
-            d[b] = make_float2(u.x - v.x, u.y - v.y);
-        }
-        __syncthreads();
-    }
-}
-
-// grid (ceil(nblocks / blocks_per_wg), rows); x [rows][N], h [rows][2][Lh], gain [rows], y [rows][2][N]
-__global__ void __launch_bounds__(256) k_fft_conv(const float* __restrict__ x, const float* __restrict__ h,
-                                                  const float* __restrict__ gain, float* __restrict__ y, int N, int Lh,
-                                                  int blocks_per_wg) {
-    __shared__ float2 d[FC_F];
-    __shared__ float2 tw[FC_F / 2];
-    const int tid = threadIdx.x, row = blockIdx.y;
-    const int nblocks = (N + FC_L - 1) / FC_L;
-    const int q0 = blockIdx.x * blocks_per_wg, q1 = min(q0 + blocks_per_wg, nblocks);
-    for (int k = tid; k < FC_F / 2; k += 256) {
-        float sn, cs;
-        sincospif(-2.0f * (float)k / (float)FC_F, &sn, &cs);
-        tw[k] = make_float2(cs, sn);
-    }
-    const float* hl = h + (long)row * 2 * Lh;
-    for (int i = tid; i < FC_F; i += 256) d[i] = i < Lh ? make_float2(hl[i], hl[Lh + i]) : make_float2(0.f, 0.f);
-    __syncthreads();
-    fft_dif(d, tw, tid);
-    float2 W[FC_PER];                                             // spectrum of h_L + i h_R, this thread's bins
-#pragma unroll
-    for (int j = 0; j < FC_PER; ++j) W[j] = d[tid + 256 * j];
-    const float g = gain[row] * (1.0f / FC_F);
-    const float* xr = x + (long)row * N;
-    float* yl = y + (long)row * 2 * N;
-    for (int q = q0; q < q1; ++q) {
-        __syncthreads();                                          // previous block's outputs / the W reads are done
-        const int lo = q * FC_L - (FC_F - FC_L);                  // segment x[lo .. lo + F)
-        for (int i = tid; i < FC_F; i += 256) {
-            const int p = lo + i;
-            d[i] = make_float2((p >= 0 && p < N) ? xr[p] : 0.f, 0.f);
-        }
-        __syncthreads();
-        fft_dif(d, tw, tid);
-#pragma unroll
-        for (int j = 0; j < FC_PER; ++j) d[tid + 256 * j] = cmul(d[tid + 256 * j], W[j]);
-        __syncthreads();
-        ifft_dit(d, tw, tid);
-        for (int i = tid; i < FC_L; i += 256) {                   // the last FC_L points of the circular result are linear
-            const int n = q * FC_L + i;
-            if (n < N) {
-                const float2 v = d[FC_F - FC_L + i];
-                yl[n] = v.x * g;
-                yl[N + n] = v.y * g;
-            }
-        }
-    }
-}
+int launch_fft_conv(const float* x, const float* h, const float* gain, float* y, int N, int Lh, int rows, hipStream_t st);
 
 // sum of the S1 rendered sources in the reference's order: ((e0 + e1) + ...) + noise (the last row)
 __device__ __forceinline__ float mix_sum(const float* __restrict__ ev, long stride, int S1, long i, float inv, bool scale) {
@@ -252,9 +166,7 @@ extern "C" int lh_render_binaural(const float* src, const float* rir, const floa
     if (hipMemsetAsync(peak, 0, sizeof(unsigned) * B, st) != hipSuccess) return LH_ERR_LAUNCH;
     if (Lh >= FC_LH_MIN && Lh <= FC_LH_MAX) {
         // room-length responses: overlap-save FFT convolution, 5 output blocks of 4096 samples per workgroup
-        const int nblocks = (N + FC_L - 1) / FC_L, bpw = 5;
-        hipLaunchKernelGGL(k_fft_conv, dim3((nblocks + bpw - 1) / bpw, B * S1), dim3(256), 0, st, src, rir, gain, events, N, Lh,
-                           bpw);
+        if (launch_fft_conv(src, rir, gain, events, N, Lh, B * S1, st) != LH_OK) return LH_ERR_LAUNCH;
     } else {
         hipLaunchKernelGGL(k_fir_causal, dim3((N + FIR_TILE - 1) / FIR_TILE, B * S1 * 2), dim3(256), 0, st, src, rir, gain,
                            events, N, Lh);

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "lookoncetohear_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "liblookonce_emu.so")
-SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_recur.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_stream.hip", "lh_comm.hip"]
+SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_recur.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_render_fft.hip", "lh_stream.hip", "lh_comm.hip"]
 
 
 def build_emu(force=False, extra_flags=(), out=OUT):
