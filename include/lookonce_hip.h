@@ -72,10 +72,12 @@ int lh_abi_version(void);
  * intra LSTM, key 1 = same for the inter LSTM, key 2 = fused intra kernel (0 = k_intra_xp, the hand-ordered
  * software-pipelined step; 2 = the previous k_ln_lstm_lin), key 3 = 0 switches off the issue-priority de-phasing of
  * the two workgroups that share a CU in k_ln_lstm_lin (default on), key 4 = query frames per attention workgroup
- * (1 / 2 = tiles of 16, 3 = 40 frames in three tiles; 0 = automatic), key 5 = fused inter kernel (0 = k_lstm_lin8p,
- * 1 = k_inter_xp, its hand-ordered twin: measured equal), key 6 = runs of consecutive tiles per utterance in
+ * (1 / 2 = tiles of 16, 3 = 40 frames in three tiles; 0 = automatic), key 5 = fused inter kernel (0 = k_inter_xp,
+ * the hand-ordered step with per-phase issue priority; 2 = the previous k_lstm_lin8p), key 6 = runs of consecutive tiles per utterance in
  * lh_deconv_istft (0 = automatic: 256 / B), key 7 = bytes of dynamic LDS added to k_intra_xp launches (timing probe:
- * one workgroup per CU), key 8 = 1: static issue priority for the odd wave slot in k_intra_xp. */
+ * one workgroup per CU), key 8 = issue priority in k_intra_xp (0 = none, 1 = static priority for the odd wave slot of a SIMD: default, 2 / 3 =
+ * every wave raised during the on-chain / off-chain phase of the step), key 9 = issue priority in k_inter_xp (0 = none,
+ * 1 / 2 = the LayerNorm / projection waves, 3 = every wave during the on-chain phase: default, 4 = off-chain phase). */
 int lh_set_tuning(int key, int value);
 
 /* Validates model_params (reference net.py:21-49 / configs/tsh.json:5-19) against the compiled constants. */

@@ -1146,7 +1146,7 @@ extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_s
     // sequence s = b*97 + f; step = frame t; row(s, t) = (b*T + t)*97 + f.  Eight-wave tiles (k_lstm_lin8p): the pass is a
     // 625-step dependent chain, two waves per SIMD cover each other's latencies
     const int nseq = B * NF;
-    if (g_tune[5] == 1)                           // hand-ordered step (lh_recur.hip): measured equal to k_lstm_lin8p (A/B only)
+    if (g_tune[5] != 2 && T >= 2)                 // hand-ordered step with per-phase issue priority (lh_recur.hip); 2 = previous kernel (A/B)
         return launch_inter_xp(x, w_pk, b_sum, wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF,
                                (hipStream_t)stream);
     hipLaunchKernelGGL(k_lstm_lin8p, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,

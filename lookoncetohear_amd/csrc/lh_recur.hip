@@ -63,9 +63,16 @@ constexpr int XP_XN = 8;
 constexpr int XP_XN = 12;      // MFMAs per k-step of the x half: 4 gates x (hi*hi, hi*lo, lo*hi)
 #endif
 
+#if defined(XP_PF1)             // A/B probe: one step ahead
+constexpr int XP_PF = 1;
+#else
+constexpr int XP_PF = 2;       // k_inter_xp: global rows are fetched two steps (~1.8 us) ahead of their use
+#endif
+
 #if defined(XP_TRACE)          // timing probe build only: s_memtime stamps of one wave of two workgroups of k_intra_xp
 __device__ unsigned long long xp_trace_buf[2 * 128 * 4];
 __device__ unsigned long long xp_wg_log[4096 * 4];       // per workgroup: start tick, end tick, HW_ID, XCC_ID
+__device__ unsigned long long xp_trace_inter[2 * 128 * 4];   // k_inter_xp, workgroup 3: wave 0 (projection role) | wave 4 (LayerNorm role)
 #define XP_STAMP(k) do { if (tr_on) tr[(it & 127) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define XP_STAMP(k) do { } while (0)
@@ -108,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
     const bool tr_on = tr_slot >= 0 && threadIdx.x == 0 && dir == 0;
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (prio) {       // A/B switch: static issue priority for one of the two workgroups that share a CU
+    if (prio == 1) {  // static issue priority for one of the two workgroups that share a CU (2 / 3: per phase, in the step)
         const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID[3:0] = wave slot
         if (hw_id & 1) __builtin_amdgcn_s_setprio(2);
     }
@@ -224,6 +231,8 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
         constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
         constexpr bool STORE = decltype(store_tag)::value;
         // ================= phase H: recurrent half on top of gx  ||  row-wise work
+        if (prio == 2) __builtin_amdgcn_s_setprio(3);
+        if (prio == 3) __builtin_amdgcn_s_setprio(0);
         XP_STAMP(0);
         xp_f16x8 hh[2], hl[2];
 #pragma unroll
@@ -288,6 +297,8 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
 #endif
         xp_zip<24>(h_mfma, h_ops);
         XP_STAMP(1);
+        if (prio == 2) __builtin_amdgcn_s_setprio(0);
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
         // ================= phase C: projection of h_{it-1} (6 MFMAs), x half of step it+1 (24)  ||  cell update of step it
         xp_f16x8 xh[2], xl[2];
         f32x4 am = f32x4{lbias, lbias, lbias, lbias};
@@ -429,7 +440,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
                                                      const float* __restrict__ blin, const float* __restrict__ h0,
                                                      const float* __restrict__ c0, float* __restrict__ hN,
                                                      float* __restrict__ cN, float* out, int nseq, int nstep, int sdiv,
-                                                     int so, int si, int ps, int dir, int accumulate) {
+                                                     int so, int si, int ps, int dir, int accumulate, int prio) {
     constexpr int NS = 16;
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * XP_AP];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * XP_AP];
@@ -437,6 +448,13 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     __shared__ __attribute__((aligned(16))) float hf[NS * XP_LSP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // A/B switch (lh_set_tuning key 9): issue priority for one role — 1 = the LayerNorm waves, 2 = the projection waves
+    if ((prio == 1 && wave >= 4) || (prio == 2 && wave < 4)) __builtin_amdgcn_s_setprio(3);
+#if defined(XP_TRACE)
+    __shared__ unsigned long long tr_all[2 * 128 * 4];
+    const bool tr_on = blockIdx.x == 3 && (threadIdx.x & 255) == 0;
+    unsigned long long* const tr = tr_all + (threadIdx.x >> 8) * 512;
+#endif
     const int s0 = blockIdx.x * NS;
     const int g4 = lane >> 4, l15 = lane & 15;
     const bool lin_wave = wave < 4;
@@ -530,11 +548,13 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
 
     // ---- prologue: x_0, x_1 normalised into the two buffers, x_2 in flight; h_{-1}; x half of step 0
     float creg[2], hreg[2];               // creg: cell state scaled by -2 log2 e
-    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+    // global rows are fetched XP_PF steps ahead of their use (one register quad per step in flight)
+    float4 carryq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     if (!lin_wave) {
         norm_store_x(0, load_row(xb, 0));
         norm_store_x(1, load_row(xb, 1));
-        carry = load_row(xb, 2);
+        carryq[0] = load_row(xb, 2);
+        if (XP_PF == 2) carryq[1] = load_row(xb, 3);
     } else {
         const int s = min(s0 + rrow, nseq - 1);
         float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -558,6 +578,10 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
         constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
         constexpr bool LIN = decltype(lin_tag)::value;
         constexpr bool STORE = decltype(store_tag)::value;
+        float4& carry = carryq[XP_PF == 2 ? cur : 0];
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        if (prio == 4) __builtin_amdgcn_s_setprio(0);
+        XP_STAMP(0);
         // ================= phase H: acc = (x half of this step, computed a step ago) + h_{it-1} W_hh^T  ||  row-wise role
         xp_f16x8 bh[2], bl[2];
 #pragma unroll
@@ -581,7 +605,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
                 [&] { done.x = carry.x + pv.x; done.y = carry.y + pv.y; },
                 [&] { done.z = carry.z + pv.z; done.w = carry.w + pv.w; },
                 [&] { if (STORE) *reinterpret_cast<float4*>(ob + step_pos(it - 2) * step_bytes + voff) = done; },
-                [&] { carry = load_row(bsrc, it - 1); });
+                [&] { carry = load_row(bsrc, it + XP_PF - 2); });
             xp_zip<12>(h_mfma, h_ops);
         } else {
             // x_{it+2} (fetched a step ago) normalised into the x half of buffer `cur`; x_{it+3} fetched
@@ -605,9 +629,9 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
                 [&] { qa = row_ror_add<2>(qa); },
                 [&] { qa = row_ror_add<1>(qa); },
                 [&] { rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qa, 1.0f / C, LN_EPS)); },
-                [&] { carry = load_row(xb, it + 3); },
                 [&] { y.x = v.x * rstd; y.y = v.y * rstd; },
                 [&] { y.z = v.z * rstd; y.w = v.w * rstd; },
+                [&] { carry = load_row(xb, it + 2 + XP_PF); },      // behind the last use of v: the fetch can land in v's registers
                 [&] { _Float16 a_, b_; split_hl(y.x, a_, b_); h4[0] = a_; l4[0] = b_; },
                 [&] { _Float16 a_, b_; split_hl(y.y, a_, b_); h4[1] = a_; l4[1] = b_; },
                 [&] { _Float16 a_, b_, c_, d_; split_hl(y.z, a_, b_); split_hl(y.w, c_, d_); h4[2] = a_; l4[2] = b_; h4[3] = c_; l4[3] = d_; },
@@ -623,6 +647,9 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
                 });
             xp_zip<12>(h_mfma, h_ops);
         }
+        XP_STAMP(1);
+        if (prio == 3) __builtin_amdgcn_s_setprio(0);
+        if (prio == 4) __builtin_amdgcn_s_setprio(3);
         // ================= phase C: [projection of h_{it-1},] x half of step it+1  ||  the two cell updates of step it
         f32x4 am = f32x4{lbias, lbias, lbias, lbias};
         constexpr int NL = LIN ? 6 : 0;
@@ -688,14 +715,16 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
             [&] { cF(M0{}); }, [&] { cF(M1{}); }, [&] { cG(M0{}); }, [&] { cG(M1{}); }, [&] { cH(M0{}); }, [&] { cH(M1{}); },
             [&] { cI(M0{}); }, [&] { cI(M1{}); });
         xp_zip<12 + NL>(c_mfma, c_ops);
+        XP_STAMP(2);
         __syncthreads();
+        XP_STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto run = [&](auto lin_tag) __attribute__((always_inline)) {
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
         step(0, B0{}, lin_tag, std::false_type{});
-        if (nstep > 1) step(1, B1{}, lin_tag, std::false_type{});
+        step(1, B1{}, lin_tag, std::false_type{});        // nstep >= 2 (launch_inter_xp): one way into the loop, exact vmcnt
         int it = 2;
         for (; it + 1 < nstep; it += 2) {
             step(it, B0{}, lin_tag, std::true_type{});
@@ -706,15 +735,21 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     if (lin_wave) run(std::true_type{});
     else run(std::false_type{});
 
+#if defined(XP_TRACE)
+    __syncthreads();
+    if (blockIdx.x == 3)
+        for (int i = threadIdx.x; i < 2 * 128 * 4; i += 512) xp_trace_inter[i] = tr_all[i];
+#endif
     // ---- drain: rows of the last two steps (projection of h_{nstep-1} still to do), final state
     const int lastb = nstep & 1;
+    float4 carry = XP_PF == 2 ? (lastb ? carryq[1] : carryq[0]) : carryq[0];      // base row of step nstep-2
     if (lin_wave) {
         if (nstep >= 2) {
             const float4 pv = *reinterpret_cast<const float4*>(&ls[(lastb ^ 1) * NS * XP_LSP + l_row]);
             *reinterpret_cast<float4*>(ob + step_pos(nstep - 2) * step_bytes + voff) =
                 make_float4(carry.x + pv.x, carry.y + pv.y, carry.z + pv.z, carry.w + pv.w);
         }
-        carry = load_row(bsrc, nstep - 1);
+        carry = XP_PF == 2 ? (lastb ? carryq[0] : carryq[1]) : load_row(bsrc, nstep - 1);
         f32x4 am = f32x4{lbias, lbias, lbias, lbias};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -745,19 +780,26 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     }
 }
 
+static int g_xp_lds_pad = 0;      // lh_set_tuning(7, bytes): dynamic LDS added to k_intra_xp launches (timing probe: 1 workgroup per CU)
+// Issue priorities (s_setprio; A/B in profiles/r03h_issue_priority.txt).  Two waves share every SIMD and the arbiter decides whose
+// instruction goes first; without a hint the wave on the recurrence's critical path loses about every other arbitration.
+static int g_xp_prio = 1;         // lh_set_tuning(8, v): k_intra_xp, 0 = none, 1 = the wave in the odd hardware slot of a SIMD runs at
+                                  // priority 2 (default), 2 / 3 = every wave at priority 3 during phase H / phase C
+static int g_xp_prio_inter = 3;   // lh_set_tuning(9, v): k_inter_xp, 0 = none, priority 3 for 1 = the LayerNorm waves, 2 = the projection
+                                  // waves, 3 = every wave during phase H (default), 4 = every wave during phase C
+
 int launch_inter_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                     const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep, int sdiv, int so,
                     int si, int ps, hipStream_t st) {
+    if (nstep < 2) return LH_ERR_ARG;             // the first two steps are peeled unconditionally
     hipLaunchKernelGGL(k_inter_xp, dim3((nseq + 15) / 16), dim3(512), 0, st, x, (const _Float16*)w_pk, b_sum,
-                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, 0, 0);
+                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, 0, 0, g_xp_prio_inter);
     return check_launch();
 }
-
-static int g_xp_lds_pad = 0;      // lh_set_tuning(7, bytes): dynamic LDS added to k_intra_xp launches (timing probe: 1 workgroup per CU)
-static int g_xp_prio = 0;         // lh_set_tuning(8, v): 1 = the wave in the odd hardware slot of a SIMD runs at issue priority 2
 int xp_set(int key, int v) {
     if (key == 7) g_xp_lds_pad = v < 0 ? 0 : v;
     if (key == 8) g_xp_prio = v;
+    if (key == 9) g_xp_prio_inter = v;
     return LH_OK;
 }
 
@@ -771,6 +813,9 @@ int launch_intra_xp(const float* x, const void* w_pk, const float* b_sum, const 
 }  // namespace lh
 
 #if defined(XP_TRACE)
+extern "C" int lh_probe_xp_trace_inter_read(unsigned long long* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::xp_trace_inter), sizeof(lh::xp_trace_inter)) == hipSuccess ? 0 : 1;
+}
 extern "C" int lh_probe_xp_trace_read(unsigned long long* host_dst) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::xp_trace_buf), sizeof(lh::xp_trace_buf)) == hipSuccess ? 0 : 1;
 }

@@ -35,15 +35,15 @@ ab)                 # same-box A/B of library builds: LIBS="_lookonce_hip_x.so _
         LOOKONCE_HIP_LIB=$R/lookoncetohear_amd/$lib timeout 200 python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-secondary --no-power --batch $b ${BENCH_ARGS:-} > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
         bench_line gpurun_out/bench_ab.json "$lib B=$b"
     done; done; done ;;
-tunes)              # same-box A/B of lh_set_tuning switches: TUNES="_ 5=1 2=1" (_ = defaults) BATCH=32 REPS=2
+tunes)              # same-box A/B of lh_set_tuning switches: TUNES="_ 5=2 8=0,9=0" (_ = defaults) BATCH=32 REPS=2
     for rep in $(seq ${REPS:-2}); do for t in ${TUNES:-_}; do for b in ${BATCH:-32}; do
         ta=""; [ "$t" != "_" ] && ta="--tune $t"
         timeout 200 python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-secondary --no-power --batch $b $ta > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
         bench_line gpurun_out/bench_ab.json "tune $t B=$b"
     done; done; done ;;
-lab)                # recurrent-kernel lab: LIBS="_lookonce_hip.so _lookonce_hip_x.so" TUNES="_ 2=1 5=1" (scripts/lab_recur.py)
+lab)                # recurrent-kernel lab: LIBS="_lookonce_hip.so _lookonce_hip_x.so" TUNES="_ 2=2 5=2 9=0" (scripts/lab_recur.py)
     for lib in ${LIBS:-_lookonce_hip.so}; do
-        LOOKONCE_HIP_LIB=$R/lookoncetohear_amd/$lib timeout 300 python scripts/lab_recur.py --tunes "${TUNES:-_ 2=1,5=1}" ${LAB_ARGS:-} 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/lab_recur.txt
+        LOOKONCE_HIP_LIB=$R/lookoncetohear_amd/$lib timeout 300 python scripts/lab_recur.py --tunes "${TUNES:-_ 2=2,5=2}" ${LAB_ARGS:-} 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/lab_recur.txt
     done ;;
 bench)              # the default bench line, as the driver runs it
     timeout 900 python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"

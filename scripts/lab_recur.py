@@ -2,7 +2,7 @@
 random activations, the random-init weights of block 0) under a list of `lh_set_tuning` settings and compares every
 setting's outputs with the first one's.  One process per library build:
 
-    LOOKONCE_HIP_LIB=lookoncetohear_amd/_lookonce_hip_x.so python scripts/lab_recur.py --tunes "_ 2=1 2=1,3=1 5=1"
+    LOOKONCE_HIP_LIB=lookoncetohear_amd/_lookonce_hip_x.so python scripts/lab_recur.py --tunes "_ 5=2 9=0 8=0"
 
 ("_" = defaults.)  Prints one line per setting; used through `scripts/gpu.sh lab`.
 """
@@ -88,7 +88,7 @@ def main():
                      f" c {(cN - r[2]).abs().max().item():.1e}  rerun {'same' if torch.equal(o1, o2) else 'DIFFERS'}")
         print(line, flush=True)
         for k in keys:
-            lib.call("lh_set_tuning", k, 1 if k == 3 else 0)       # back to the defaults
+            lib.call("lh_set_tuning", k, {3: 1, 8: 1, 9: 3}.get(k, 0))       # back to the defaults
 
 
 if __name__ == "__main__":

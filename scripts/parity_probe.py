@@ -1,5 +1,5 @@
 """GPU probe (test tooling): B=32 x 5 s forward under a list of lh_set_tuning settings against the fp64 CPU oracle on two
-rows, and against each other on all rows.    python scripts/parity_probe.py "_" "2=1,5=1"   (LOOKONCE_HIP_LIB selects the build)"""
+rows, and against each other on all rows.    python scripts/parity_probe.py "_" "2=2,5=2"   (LOOKONCE_HIP_LIB selects the build)"""
 import os
 import sys
 

@@ -112,8 +112,9 @@ def test_previous_fused_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     assert (y - yo).abs().max() < TOL
 
 
-def test_pipelined_inter_kernel(emu_net, oracle_cfg_sd):
-    """k_inter_xp (lh_recur.hip) selected with lh_set_tuning(5, 1): B=6 (582 sequences = 37 tiles, last one ragged; above
+@pytest.mark.parametrize("tune5", [0, 2], ids=["k_inter_xp", "k_lstm_lin8p"])
+def test_fused_inter_kernels(emu_net, oracle_cfg_sd, tune5):
+    """k_inter_xp (lh_recur.hip, the default) and the previous k_lstm_lin8p (lh_set_tuning(5, 2)): B=6 (582 sequences = 37 tiles, last one ragged; above
     the per-sequence mat-vec kernel's batch limit), T=7, carried (h0, c0) in and (hN, cN) out against the oracle."""
     cfg, sd = oracle_cfg_sd
     lib = emu_net._lib_override
@@ -121,7 +122,7 @@ def test_pipelined_inter_kernel(emu_net, oracle_cfg_sd):
     d = synth.batch(list(range(20, 20 + B)), 128 * T + 64)
     st = O.random_state(cfg, B, 13)
     yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
-    lib.call("lh_set_tuning", 5, 1)
+    lib.call("lh_set_tuning", 5, tune5)
     try:
         y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
     finally:
