@@ -232,8 +232,8 @@ def test_backend_runs_of_tiles(emu_net, oracle_cfg_sd):
     and the automatic choice (one run per tile here) must all reproduce the oracle's waveform and next state."""
     cfg, sd = oracle_cfg_sd
     lib = emu_net._lib_override
-    B, T = 2, 37
-    d = synth.batch([8, 9], 128 * T + 64)
+    B, T = 1, 37
+    d = synth.batch([8], 128 * T + 64)
     st = O.random_state(cfg, B, 6)
     yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
     fo = O.flat_state(so)
