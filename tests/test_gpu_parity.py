@@ -97,14 +97,14 @@ def test_golden_full_clip_and_stages(net, golden, oracle_cfg_sd):
 def test_batch32_invariance_and_oracle(net, oracle_cfg_sd):
     """BASELINE config 3 size (B=32 x 5 s): utterances are independent, so every row of the batched run must
     equal the same utterance run alone (different tile shapes / kernel instantiations, so equal up to fp32
-    contraction order: 2e-5), rows of a repeated run must be bit-identical (no races), and two rows are checked
+    contraction order: 2e-5), rows of a repeated run must be bit-identical (no races), and eight rows are checked
     against the CPU oracle at full length."""
     cfg, sd = oracle_cfg_sd
     idx = list(range(100, 132))
     d = synth.batch(idx, 80000)
     y = net(d["mixture"].to(DEV), d["embedding_gt"].to(DEV))
     assert tuple(y.shape) == (32, 2, 80000) and torch.isfinite(y).all()
-    for _ in range(3):          # deterministic: no races, no atomics (a rare LDS-read race showed up in ~0.3 % of rows)
+    for _ in range(3):          # deterministic: no races, no atomics
         y_again = net(d["mixture"].to(DEV), d["embedding_gt"].to(DEV))
         assert torch.equal(y, y_again)
     for r in (0, 17, 31):
@@ -112,11 +112,12 @@ def test_batch32_invariance_and_oracle(net, oracle_cfg_sd):
         e = _err(y1[0], y[r].cpu())
         print("batch-of-1 vs row", r, e)
         assert e < 2e-5, r
-    for r in (5, 31):
-        yo = O.forward(cfg, sd, d["mixture"][r:r + 1], d["embedding_gt"][r:r + 1], fast_lstm=True)
-        e = _err(y[r:r + 1], yo)
+    rows = [0, 5, 9, 14, 17, 22, 27, 31]        # a quarter of the batch against the oracle (one batched fp64 CPU forward)
+    yo = O.forward(cfg, sd, d["mixture"][rows], d["embedding_gt"][rows], fast_lstm=True)
+    for i, r in enumerate(rows):
+        e = _err(y[r:r + 1], yo[i:i + 1])
         print("row", r, e)
-        assert e < TOL
+        assert e < TOL, r
 
 
 def test_streaming_full_length_equals_offline(net):
