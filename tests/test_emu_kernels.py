@@ -395,3 +395,32 @@ def test_streamer_refuses_stale_weights(emu_net):
     finally:
         with torch.no_grad():
             p.copy_(keep)
+
+
+def test_inter_xp_shortest_sequences(emu_net):
+    """k_inter_xp peels its first two steps and has a two-step unrolled loop with a tail: T = 2, 3, 4, 5 (no loop / tail only /
+    one loop pass / loop + tail) with carried state and a ragged last tile, against the previous kernel (lh_set_tuning(5, 2));
+    T = 1 must route to the previous kernel (the hand-ordered one needs two steps)."""
+    lib = emu_net._lib_override
+    bp = emu_net._weights(torch.device("cpu"))["blocks"][1]
+    P = lambda t: t.data_ptr()
+    B = 1                                            # 97 sequences = 7 tiles, the last one with a single live row
+    g = torch.Generator().manual_seed(21)
+    for T in (1, 2, 3, 4, 5):
+        x = torch.randn(B, T, 97, 64, generator=g)
+        h0 = torch.randn(B * 97, 64, generator=g) * 0.3
+        c0 = torch.randn(B * 97, 64, generator=g) * 0.3
+        res = []
+        for tune in (0, 2):
+            out, hN, cN = torch.zeros_like(x), torch.zeros_like(h0), torch.zeros_like(c0)
+            lib.call("lh_set_tuning", 5, tune)
+            try:
+                lib.call("lh_inter_block", P(x), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
+                         P(bp["inter_lin_b"]), P(h0), P(c0), P(hN), P(cN), P(out), B, T, 0)
+            finally:
+                lib.call("lh_set_tuning", 5, 0)
+            res.append((out, hN, cN))
+        for a, b in zip(*res):
+            assert torch.isfinite(a).all() and (a - b).abs().max() < 2e-6, T
+        if T == 1:
+            assert all(torch.equal(a, b) for a, b in zip(*res))
