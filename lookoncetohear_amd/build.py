@@ -7,6 +7,7 @@ Output: lookoncetohear_amd/_lookonce_hip.so (git-ignored, but it travels to the 
 from __future__ import annotations
 
 import os
+import shutil
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -45,8 +46,12 @@ def unsafe_packed_fp32(lib_path: str):
     import tempfile
     llvm = "/opt/rocm/lib/llvm/bin"
     with tempfile.TemporaryDirectory() as td:
-        # newer llvm-objdump finds the fat-binary section itself
-        out = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--offloading", lib_path], capture_output=True, text=True)
+        # newer llvm-objdump finds the fat-binary section itself — and writes every bundle it extracts next to its input:
+        # work on a copy in the temporary directory
+        tmp_lib = os.path.join(td, os.path.basename(lib_path))
+        shutil.copyfile(lib_path, tmp_lib)
+        out = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--offloading", tmp_lib], capture_output=True, text=True,
+                             cwd=td)
         text = out.stdout
         if "v_mfma" not in text:                        # older llvm-objdump: extract the code object by hand
             raw = open(lib_path, "rb").read()

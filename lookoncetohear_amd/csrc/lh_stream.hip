@@ -6,19 +6,113 @@
 // (frame, direction) and treats the step as what it is, a 256 x 64 mat-vec:
 //   1. the input half of all 97 steps is hoisted out of the recurrence: G_x = LN(x) W_ih'^T + b as ONE
 //      [97 x 64] x [64 x 256] split-precision MFMA GEMM into LDS (LayerNorm affine folded into W_ih', b);
-//   2. 512 threads = 256 gate rows x 2 halves of the k range: a thread keeps its half row of W_hh (32 fp32 registers)
-//      and adds it to h_{t-1} with plain fp32 FMAs, h read as LDS broadcasts; the rows are laid out so that the two
-//      halves and the four gates of a hidden unit sit in one 16-lane row — DPP row rotations add the halves and bring
-//      the gates together, 8 lanes per wave update the cell, ONE barrier per step.
+//   2. the step is latency, not throughput: ONE wave per SIMD (256 threads) and four lanes per hidden unit.  Lane
+//      (unit u, slice s) keeps the 16-wide k slice s of the unit's four gate rows of W_hh (64 fp32 registers), reads its
+//      16 values of h_{t-1} from LDS (4 broadcast reads instead of the 8 of a half row) and does the 64 FMAs as 32 packed
+//      ones (v_pk_fma_f32 on whole register pairs: the safe form, build.py).  The four partial sums per gate are then
+//      REDUCE-SCATTERED over the quad with DPP quad permutes (lane s ends up with the full sum of gate s: 6 selects + 3
+//      adds, against 12 adds for an all-reduce), so every lane evaluates ONE gate non-linearity (2 transcendentals per
+//      lane and step instead of 8 on one lane in eight), and two more quad permutes bring i*g and o to the lane that holds
+//      the cell state.  4 transcendental + ~70 other instructions per step on an otherwise empty SIMD, one barrier:
+//      0.49 -> ~0.3 us per step (profiles/r03k_*).
 // Reference: tfgridnet_causal.py:505-512 (intra_norm + intra_rnn); output in the unfused layout [rows][128] consumed
 // by lh_linear_res.
 #include "lh_split.h"
 
 namespace lh {
 
-constexpr int IS_GP = 4 * H;               // 256 gate columns
-constexpr int IS_NT = 512;                 // threads: gate column x half of the k range
+constexpr int IS_GP = 4 * H;               // 256 gate columns, column 4 u + g = gate g of hidden unit u (weights.py)
+constexpr int IS_NT = 512;                 // threads of the staging / GEMM phases
+constexpr int IS_NW = IS_NT / 64;
+constexpr int IS_NR = 256;                 // threads of the recurrence (hidden unit x k slice): waves 0..3, one per SIMD; the
+                                           // other four only keep the step barrier company
 constexpr int IS_NLD = (NF * 16 + IS_NT - 1) / IS_NT;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// value of lane (l ^ 1) / (l ^ 2) of the same quad: DPP quad_perm [1,0,3,2] / [2,3,0,1]
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+constexpr int QP_XOR1 = 0xB1, QP_XOR2 = 0x4E;
+
+// rows 4 u + g (g < 4) of W_hh [256][64], columns [16 s, 16 s + 16), as register pairs
+__device__ __forceinline__ void quad_load_w(const float* __restrict__ whh, int u, int s, f32x2 (&w)[4][8]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const float4 v = *reinterpret_cast<const float4*>(whh + (long)(4 * u + g) * H + 16 * s + 4 * k4);
+            w[g][2 * k4] = f32x2{v.x, v.y};
+            w[g][2 * k4 + 1] = f32x2{v.z, v.w};
+        }
+}
+
+// One LSTM step of hidden unit u on its quad of lanes.  hs16 = this lane's 16 values of h_{t-1} (LDS), gx = the input half
+// (+ bias) of gate s of the unit.  Returns h_t in the lane with s == 1, which is also where `c` is the cell state (the other
+// three lanes carry bounded don't-care values through the same instructions).  PyTorch gate order i, f, g, o = s.
+// QS_PROBE = n: timing probes of the step's parts (WRONG results on purpose; scripts/lab_stream.py): 1 = 4 of the 32 packed
+// FMAs, 2 = no transcendentals, 3 = h from registers instead of LDS, 4 = no barrier, 5 = no DPP exchanges
+#if !defined(QS_PROBE)
+#define QS_PROBE 0
+#endif
+#if QS_PROBE == 5
+#define quad_perm quad_perm_off
+template <int CTRL>
+__device__ __forceinline__ float quad_perm_off(float v) { return v; }
+#endif
+#if QS_PROBE == 4
+#define QS_SYNC() do { } while (0)
+#else
+#define QS_SYNC() __syncthreads()
+#endif
+__device__ __forceinline__ float quad_step(const f32x2 (&w)[4][8], const float* hs16, float gx, float& c, int s) {
+    f32x2 h2[8];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+#if QS_PROBE == 3
+        const float4 v = make_float4(c, gx, c, gx);
+#else
+        const float4 v = *reinterpret_cast<const float4*>(hs16 + 4 * k4);
+#endif
+        h2[2 * k4] = f32x2{v.x, v.y};
+        h2[2 * k4 + 1] = f32x2{v.z, v.w};
+    }
+#if defined(__AMDGCN__)
+    // all of h into registers first, ONE wait, then the FMAs: left to itself the scheduler interleaves read / wait / FMAs
+    // and exposes the LDS latency every time
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    f32x2 a2[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < (QS_PROBE == 1 ? 1 : 8); ++kk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a2[g] = __builtin_elementwise_fma(w[g][kk], h2[kk], a2[g]);
+    const float a0 = a2[0][0] + a2[0][1], a1 = a2[1][0] + a2[1][1], a2s = a2[2][0] + a2[2][1], a3 = a2[3][0] + a2[3][1];
+    // reduce-scatter over the quad: after the first exchange a lane holds the pair sums of the two gates of its parity,
+    // after the second the quad sum of gate s
+    const bool b0 = s & 1, b1 = s & 2;
+    float ka = b0 ? a1 : a0, kb = b0 ? a3 : a2s;
+    ka += quad_perm<QP_XOR1>(b0 ? a0 : a1);
+    kb += quad_perm<QP_XOR1>(b0 ? a2s : a3);
+    const float pre = (b1 ? kb : ka) + quad_perm<QP_XOR2>(b1 ? ka : kb) + gx;
+    // sigma(x) = 1 / (1 + 2^(-log2e x)) for i, f, o;  tanh(x) = 2 / (1 + 2^(-2 log2e x)) - 1 for g
+    const float km = s == 2 ? -2.0f * LOG2E : -LOG2E, ma = s == 2 ? 2.0f : 1.0f, aa = s == 2 ? -1.0f : 0.0f;
+#if QS_PROBE == 2
+    const float val = fmaf(fmaf(km * pre, 0.25f, 0.5f), ma, aa);
+#else
+    const float val = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(km * pre)), ma, aa);
+#endif
+    const float vb = quad_perm<QP_XOR2>(val);           // lane 0 (i): tanh(g);  lane 1 (f): sigma(o)
+    const float ig = quad_perm<QP_XOR1>(val * vb);      // lane 1: sigma(i) tanh(g)
+    c = fmaf(val, c, ig);                               // lane 1: c' = sigma(f) c + sigma(i) tanh(g)
+#if QS_PROBE == 2
+    return vb * (0.5f * c);
+#else
+    return vb * tanh_f(c);                              // lane 1: h' = sigma(o) tanh(c')
+#endif
+}
 
 // grid = n_frames * 2 (direction = blockIdx & 1), block 512
 __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict__ x, const _Float16* __restrict__ wih_pk,
@@ -32,18 +126,10 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
     const int frame = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* xf = x + (long)frame * NF * C;
 
-    // Thread tid = 64 w + 16 r + 8 u + 2 g + kh owns gate g of hidden unit 8 w + 2 r + u for the k range
-    // [32 kh, 32 kh + 32): its half row of W_hh stays in 32 registers (weights.py lays the rows out in thread order).
-    const int kh = tid & 1;
-    float wr[H / 2];
-    {
-        const float* wp = whh + ((long)dir * IS_NT + tid) * (H / 2);
-#pragma unroll
-        for (int k4 = 0; k4 < H / 8; ++k4) {
-            const float4 v = *reinterpret_cast<const float4*>(wp + k4 * 4);
-            wr[k4 * 4 + 0] = v.x; wr[k4 * 4 + 1] = v.y; wr[k4 * 4 + 2] = v.z; wr[k4 * 4 + 3] = v.w;
-        }
-    }
+    // Thread tid = 4 u + s < 256: hidden unit u, k slice s (quad_step)
+    const int unit = (tid & (IS_NR - 1)) >> 2, qs = tid & 3;
+    f32x2 wr[4][8];
+    quad_load_w(whh + (long)dir * IS_GP * H, unit, qs, wr);
 
     // ---- LayerNorm over the 64 channels of every (frame, f) row (affine folded into the weights), split to fp16 hi/lo
     for (int i = tid; i < FR_A; i += IS_NT) { ahi[i] = (_Float16)0.f; alo[i] = (_Float16)0.f; }
@@ -62,10 +148,10 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
     if (tid < H) hs[0][tid] = 0.f;
     __syncthreads();
 
-    // ---- G_x[p][n] = b[n] + LN(x)[p] . W_ih'[n]: wave w owns column tiles 2w, 2w+1 (columns in (tid >> 1) order)
+    // ---- G_x[p][n] = b[n] + LN(x)[p] . W_ih'[n]: wave w owns column tiles 2w, 2w+1
 #pragma unroll 1
-    for (int i = 0; i < 2; ++i) {
-        const int nt = 2 * wave + i;
+    for (int i = 0; i < 16 / IS_NW; ++i) {
+        const int nt = (16 / IS_NW) * wave + i;
         f16x8 wh[2], wl[2];
         load_w<2>(wih_pk + (long)dir * 16 * 2 * 64 * 16, nt, lane, wh, wl);
         const float bz = b_sum[dir * IS_GP + nt * 16 + l15];
@@ -82,41 +168,21 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
     __syncthreads();
 
     // ---- recurrence: zero initial state (the intra LSTM carries nothing between frames)
+    if (tid >= IS_NR) {
+        for (int it = 0; it < NF; ++it) QS_SYNC();
+        return;
+    }
     float c = 0.f;
-    const int unit = wave * 8 + g4 * 2 + (l15 >> 3);
     float* hrow = h_out + ((long)frame * NF) * 2 * H + dir * H + unit;
     for (int it = 0; it < NF; ++it) {
         const int p = dir ? NF - 1 - it : it;
-        const float* hp = hs[it & 1] + kh * (H / 2);
-        float a0 = kh ? 0.f : gxs[p * IS_GP + (tid >> 1)], a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        // this half of h_{t-1} into registers first (two addresses per wave: broadcast reads), ONE wait, then the FMAs:
-        // left to itself the scheduler interleaves read / wait / 4 FMAs and exposes the LDS latency every time
-        float4 hreg[H / 8];
-#pragma unroll
-        for (int k4 = 0; k4 < H / 8; ++k4) hreg[k4] = *reinterpret_cast<const float4*>(hp + k4 * 4);
-#if defined(__AMDGCN__)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-        for (int k4 = 0; k4 < H / 8; ++k4) {
-            a0 = fmaf(wr[k4 * 4 + 0], hreg[k4].x, a0);
-            a1 = fmaf(wr[k4 * 4 + 1], hreg[k4].y, a1);
-            a2 = fmaf(wr[k4 * 4 + 2], hreg[k4].z, a2);
-            a3 = fmaf(wr[k4 * 4 + 3], hreg[k4].w, a3);
-        }
-        const float part = (a0 + a1) + (a2 + a3);
-        // DPP row rotations (a few cycles each, no LDS crossbar): the other k half sits one lane up, the gates f, g, o of
-        // this lane's unit 2, 4, 6 lanes up
-        const float gate = part + row_ror_mov<15>(part);
-        const float gf = row_ror_mov<14>(gate), gg = row_ror_mov<12>(gate), go = row_ror_mov<10>(gate);
-        if ((l15 & 7) == 0) {
-            float hv;
-            lstm_cell(gate, gf, gg, go, c, hv);
+        const float gx = gxs[p * IS_GP + tid];
+        const float hv = quad_step(wr, hs[it & 1] + 16 * qs, gx, c, qs);
+        if (qs == 1) {
             hs[(it + 1) & 1][unit] = hv;
             hrow[(long)p * 2 * H] = hv;
         }
-        __syncthreads();
+        QS_SYNC();
     }
 }
 
@@ -125,7 +191,7 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
 // Linear(64->64) -> + residual  (tfgridnet_causal.py:521-538), one workgroup per sequence (b, f).
 // The tiled kernel (k_ln_lstm_lin) needs 16 sequences per workgroup: at batch 1 that is 7 workgroups walking 625
 // steps at ~1.1 us each (0.7 ms per block, 2.1 of the 3.0 ms forward).  Here every sequence gets its own CU and the
-// step is the same 256 x 64 mat-vec as in k_intra_stream; the time axis is cut into chunks of 64 steps whose input
+// step is the same quad-lane 256 x 64 mat-vec as in k_intra_stream (quad_step); the time axis is cut into chunks of 64 steps whose input
 // half (LN(x) W_ih'^T + b) and output projection (h W_lin^T + b + residual) run as split-precision MFMA GEMMs before
 // and after the chunk's recurrence.
 // ------------------------------------------------------------------------------------------------------
@@ -152,18 +218,10 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
     float* os = out + ((long)b * T * NF + f) * C;
     const long tstride = (long)NF * C;
 
-    const int kh = tid & 1;
-    float wr[H / 2];
-    {
-        const float* wp = whh + (long)tid * (H / 2);
-#pragma unroll
-        for (int k4 = 0; k4 < H / 8; ++k4) {
-            const float4 v = *reinterpret_cast<const float4*>(wp + k4 * 4);
-            wr[k4 * 4 + 0] = v.x; wr[k4 * 4 + 1] = v.y; wr[k4 * 4 + 2] = v.z; wr[k4 * 4 + 3] = v.w;
-        }
-    }
-    const int unit = wave * 8 + g4 * 2 + (l15 >> 3);
-    const bool cell_lane = (l15 & 7) == 0;
+    const int unit = (tid & (IS_NR - 1)) >> 2, qs = tid & 3;            // hidden unit, k slice (quad_step): threads < 256
+    f32x2 wr[4][8];
+    quad_load_w(whh, unit, qs, wr);
+    const bool cell_lane = qs == 1 && tid < IS_NR;
     float c = cell_lane ? c0[(long)seq * H + unit] : 0.f;
     if (tid < H) hs[0][tid] = h0[(long)seq * H + tid];
     int hb = 0;                                                          // hs buffer holding h_{t-1}
@@ -185,8 +243,8 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
         __syncthreads();
         // ---- G_x[step][n] = b[n] + LN(x)[step] . W_ih'[n]: wave w owns column tiles 2w, 2w+1
 #pragma unroll 1
-        for (int i = 0; i < 2; ++i) {
-            const int nt = 2 * wave + i;
+        for (int i = 0; i < 16 / IS_NW; ++i) {
+            const int nt = (16 / IS_NW) * wave + i;
             f16x8 wh[2], wl[2];
             load_w<2>(wih_pk, nt, lane, wh, wl);
             const float bz = b_sum[nt * 16 + l15];
@@ -199,43 +257,29 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
         }
         __syncthreads();
         // ---- recurrence over the chunk's steps (see k_intra_stream); h_t also goes into the projection's A image
-        for (int it = 0; it < nst; ++it) {
-            const float* hp = hs[hb] + kh * (H / 2);
-            float a0 = kh ? 0.f : gxs[it * IS_GP + (tid >> 1)], a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            float4 hreg[H / 8];
-#pragma unroll
-            for (int k4 = 0; k4 < H / 8; ++k4) hreg[k4] = *reinterpret_cast<const float4*>(hp + k4 * 4);
-#if defined(__AMDGCN__)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int k4 = 0; k4 < H / 8; ++k4) {
-                a0 = fmaf(wr[k4 * 4 + 0], hreg[k4].x, a0);
-                a1 = fmaf(wr[k4 * 4 + 1], hreg[k4].y, a1);
-                a2 = fmaf(wr[k4 * 4 + 2], hreg[k4].z, a2);
-                a3 = fmaf(wr[k4 * 4 + 3], hreg[k4].w, a3);
+        if (tid >= IS_NR) {
+            for (int it = 0; it < nst; ++it) QS_SYNC();
+            hb ^= nst & 1;
+        } else {
+            for (int it = 0; it < nst; ++it) {
+                const float gx = gxs[it * IS_GP + tid];
+                const float hv = quad_step(wr, hs[hb] + 16 * qs, gx, c, qs);
+                if (cell_lane) {
+                    hs[hb ^ 1][unit] = hv;
+                    _Float16 hh, hl_;
+                    split_hl(hv, hh, hl_);
+                    const int idx = a_index<IM_TC>(it, unit);
+                    hhi[idx] = hh;
+                    hlo[idx] = hl_;
+                }
+                hb ^= 1;
+                QS_SYNC();
             }
-            const float part = (a0 + a1) + (a2 + a3);
-            const float gate = part + row_ror_mov<15>(part);
-            const float gf = row_ror_mov<14>(gate), gg = row_ror_mov<12>(gate), go = row_ror_mov<10>(gate);
-            if (cell_lane) {
-                float hv;
-                lstm_cell(gate, gf, gg, go, c, hv);
-                hs[hb ^ 1][unit] = hv;
-                _Float16 hh, hl_;
-                split_hl(hv, hh, hl_);
-                const int idx = a_index<IM_TC>(it, unit);
-                hhi[idx] = hh;
-                hlo[idx] = hl_;
-            }
-            hb ^= 1;
-            __syncthreads();
         }
         // ---- projection + residual: out[step][o] = x[step][o] + b[o] + sum_u h[step][u] W_lin[o][u]; 16 (row tile,
-        //      column tile) products over the 8 waves
+        //      column tile) products over the waves
 #pragma unroll 1
-        for (int p = wave; p < (IM_TC / 16) * 4; p += 8) {
+        for (int p = wave; p < (IM_TC / 16) * 4; p += IS_NW) {
             const int mt = p >> 2, nt = p & 3;
             f16x8 wh[2], wl[2];
             load_w<2>(wlin_pk, nt, lane, wh, wl);

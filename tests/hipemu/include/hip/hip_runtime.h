@@ -331,6 +331,10 @@ template <class T> static inline T __shfl_up(T v, int d, int width = 64) {
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu::mfma_16x16x32_f16((a), (b), (c))
 // DPP row_ror:N (dpp_ctrl 0x121..0x12F): lane i of each 16-lane row reads lane (i - N) mod 16 of its row
 static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if (ctrl >= 0 && ctrl <= 0xFF && row_mask == 0xf && bank_mask == 0xf) {      // quad_perm: lane l of a quad reads lane (ctrl >> 2l) & 3
+        int l = hipemu::lane_id();
+        return hipemu::shfl_any(src, (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3));
+    }
     if (ctrl < 0x121 || ctrl > 0x12F || row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "hipemu: unsupported DPP ctrl %x\n", ctrl); abort(); }
     int l = hipemu::lane_id();
     int n = ctrl - 0x120;
