@@ -34,23 +34,34 @@ template <int CTRL>
 __device__ __forceinline__ float quad_perm(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
-constexpr int QP_XOR1 = 0xB1, QP_XOR2 = 0x4E;
+constexpr int QP_XOR1 = 0xB1, QP_XOR2 = 0x4E, QP_XOR3 = 0x1B;
 
-// rows 4 u + g (g < 4) of W_hh [256][64], columns [16 s, 16 s + 16), as register pairs
+// exponent factor of gate g (PyTorch order i, f, g, o): sigma(x) = 1 / (1 + 2^(-log2e x)), tanh(x) = 2 / (1 + 2^(-2 log2e x)) - 1
+__device__ __forceinline__ float quad_gate_scale(int g) { return g == 2 ? -2.0f * LOG2E : -LOG2E; }
+constexpr float QS_K2 = -2.0f * LOG2E;     // the cell state is carried times this factor: tanh(c) needs no multiply
+
+// Slot j of lane (u, s) holds the row of gate j ^ s of unit u (row 4 u + (j ^ s) of W_hh [256][64]), columns [16 s, 16 s + 16),
+// times the gate's exponent factor: with the gates XOR-rotated by the slice index, lane s finds the partial sums of ITS gate
+// in slot x of lane s ^ x — the reduce-scatter is three DPP adds and no selects.
 __device__ __forceinline__ void quad_load_w(const float* __restrict__ whh, int u, int s, f32x2 (&w)[4][8]) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int j = 0; j < 4; ++j) {
+        const int g = j ^ s;
+        const float km = quad_gate_scale(g);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const float4 v = *reinterpret_cast<const float4*>(whh + (long)(4 * u + g) * H + 16 * s + 4 * k4);
-            w[g][2 * k4] = f32x2{v.x, v.y};
-            w[g][2 * k4 + 1] = f32x2{v.z, v.w};
+            w[j][2 * k4] = f32x2{km * v.x, km * v.y};
+            w[j][2 * k4 + 1] = f32x2{km * v.z, km * v.w};
         }
+    }
 }
 
-// One LSTM step of hidden unit u on its quad of lanes.  hs16 = this lane's 16 values of h_{t-1} (LDS), gx = the input half
-// (+ bias) of gate s of the unit.  Returns h_t in the lane with s == 1, which is also where `c` is the cell state (the other
-// three lanes carry bounded don't-care values through the same instructions).  PyTorch gate order i, f, g, o = s.
+// One LSTM step of hidden unit u on its quad of lanes.  hs16 = this lane's 16 values of h_{t-1} (LDS), gxs = the input half
+// (+ bias) of gate s of the unit TIMES quad_gate_scale(s).  Returns h_t in the lane with s == 1, which is also where `cs` =
+// QS_K2 * cell state lives (the other three lanes run the same instructions on don't-care values that nothing reads; lane 2's
+// may overflow to inf / NaN).
+// PyTorch gate order i, f, g, o = s.
 // QS_PROBE = n: timing probes of the step's parts (WRONG results on purpose; scripts/lab_stream.py): 1 = 4 of the 32 packed
 // FMAs, 2 = no transcendentals, 3 = h from registers instead of LDS, 4 = no barrier, 5 = no DPP exchanges
 #if !defined(QS_PROBE)
@@ -66,12 +77,12 @@ __device__ __forceinline__ float quad_perm_off(float v) { return v; }
 #else
 #define QS_SYNC() __syncthreads()
 #endif
-__device__ __forceinline__ float quad_step(const f32x2 (&w)[4][8], const float* hs16, float gx, float& c, int s) {
+__device__ __forceinline__ float quad_step(const f32x2 (&w)[4][8], const float* hs16, float gxs, float& cs, int s) {
     f32x2 h2[8];
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
 #if QS_PROBE == 3
-        const float4 v = make_float4(c, gx, c, gx);
+        const float4 v = make_float4(cs, gxs, cs, gxs);
 #else
         const float4 v = *reinterpret_cast<const float4*>(hs16 + 4 * k4);
 #endif
@@ -89,28 +100,32 @@ __device__ __forceinline__ float quad_step(const f32x2 (&w)[4][8], const float* 
     for (int kk = 0; kk < (QS_PROBE == 1 ? 1 : 8); ++kk)
 #pragma unroll
         for (int g = 0; g < 4; ++g) a2[g] = __builtin_elementwise_fma(w[g][kk], h2[kk], a2[g]);
-    const float a0 = a2[0][0] + a2[0][1], a1 = a2[1][0] + a2[1][1], a2s = a2[2][0] + a2[2][1], a3 = a2[3][0] + a2[3][1];
-    // reduce-scatter over the quad: after the first exchange a lane holds the pair sums of the two gates of its parity,
-    // after the second the quad sum of gate s
-    const bool b0 = s & 1, b1 = s & 2;
-    float ka = b0 ? a1 : a0, kb = b0 ? a3 : a2s;
-    ka += quad_perm<QP_XOR1>(b0 ? a0 : a1);
-    kb += quad_perm<QP_XOR1>(b0 ? a2s : a3);
-    const float pre = (b1 ? kb : ka) + quad_perm<QP_XOR2>(b1 ? ka : kb) + gx;
-    // sigma(x) = 1 / (1 + 2^(-log2e x)) for i, f, o;  tanh(x) = 2 / (1 + 2^(-2 log2e x)) - 1 for g
-    const float km = s == 2 ? -2.0f * LOG2E : -LOG2E, ma = s == 2 ? 2.0f : 1.0f, aa = s == 2 ? -1.0f : 0.0f;
-#if QS_PROBE == 2
-    const float val = fmaf(fmaf(km * pre, 0.25f, 0.5f), ma, aa);
-#else
-    const float val = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(km * pre)), ma, aa);
+    // horizontal sums; one half made opaque: the compiler otherwise forms v_pk_add_f32 with the halves of src1 crossed
+    // (op_sel:[0,1] — the unsafe form, build.py)
+    auto hsum = [](f32x2 v) {
+        float lo = v[0], hi = v[1];
+#if defined(__AMDGCN__)
+        asm("" : "+v"(hi));
 #endif
-    const float vb = quad_perm<QP_XOR2>(val);           // lane 0 (i): tanh(g);  lane 1 (f): sigma(o)
-    const float ig = quad_perm<QP_XOR1>(val * vb);      // lane 1: sigma(i) tanh(g)
-    c = fmaf(val, c, ig);                               // lane 1: c' = sigma(f) c + sigma(i) tanh(g)
+        return lo + hi;
+    };
+    const float a0 = hsum(a2[0]), a1 = hsum(a2[1]), a2s = hsum(a2[2]), a3 = hsum(a2[3]);
+    // reduce-scatter over the quad: slot x of lane s ^ x is a partial sum of gate s
+    const float pre = ((a0 + quad_perm<QP_XOR1>(a1)) + (quad_perm<QP_XOR2>(a2s) + quad_perm<QP_XOR3>(a3))) + gxs;
+    // lane 2 (g): K2 tanh = K2 (2 r - 1); the others: sigma = r
+    const float ma = s == 2 ? 2.0f * QS_K2 : 1.0f, aa = s == 2 ? -QS_K2 : 0.0f;
 #if QS_PROBE == 2
-    return vb * (0.5f * c);
+    const float val = fmaf(fmaf(pre, 0.25f, 0.5f), ma, aa);
 #else
-    return vb * tanh_f(c);                              // lane 1: h' = sigma(o) tanh(c')
+    const float val = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre)), ma, aa);
+#endif
+    const float vb = quad_perm<QP_XOR2>(val);           // lane 0 (i): K2 tanh(g);  lane 1 (f): sigma(o)
+    const float ig = quad_perm<QP_XOR1>(val * vb);      // lane 1: K2 sigma(i) tanh(g)
+    cs = fmaf(val, cs, ig);                             // lane 1: K2 c' = sigma(f) K2 c + K2 sigma(i) tanh(g)
+#if QS_PROBE == 2
+    return vb * (0.5f * cs);
+#else
+    return vb * fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cs)), -1.0f);      // lane 1: h' = sigma(o) tanh(c')
 #endif
 }
 
@@ -172,11 +187,12 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
         for (int it = 0; it < NF; ++it) QS_SYNC();
         return;
     }
-    float c = 0.f;
+    float c = 0.f;                                      // (scaled by QS_K2; zero either way)
+    const float gscale = quad_gate_scale(qs);
     float* hrow = h_out + ((long)frame * NF) * 2 * H + dir * H + unit;
     for (int it = 0; it < NF; ++it) {
         const int p = dir ? NF - 1 - it : it;
-        const float gx = gxs[p * IS_GP + tid];
+        const float gx = gscale * gxs[p * IS_GP + tid];
         const float hv = quad_step(wr, hs[it & 1] + 16 * qs, gx, c, qs);
         if (qs == 1) {
             hs[(it + 1) & 1][unit] = hv;
@@ -222,7 +238,8 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
     f32x2 wr[4][8];
     quad_load_w(whh, unit, qs, wr);
     const bool cell_lane = qs == 1 && tid < IS_NR;
-    float c = cell_lane ? c0[(long)seq * H + unit] : 0.f;
+    float c = cell_lane ? QS_K2 * c0[(long)seq * H + unit] : 0.f;       // carried times QS_K2
+    const float gscale = quad_gate_scale(qs);
     if (tid < H) hs[0][tid] = h0[(long)seq * H + tid];
     int hb = 0;                                                          // hs buffer holding h_{t-1}
 
@@ -262,7 +279,7 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
             hb ^= nst & 1;
         } else {
             for (int it = 0; it < nst; ++it) {
-                const float gx = gxs[it * IS_GP + tid];
+                const float gx = gscale * gxs[it * IS_GP + tid];
                 const float hv = quad_step(wr, hs[hb] + 16 * qs, gx, c, qs);
                 if (cell_lane) {
                     hs[hb ^ 1][unit] = hv;
@@ -293,7 +310,7 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
         __syncthreads();
     }
     if (tid < H) hN[(long)seq * H + tid] = hs[hb][tid];
-    if (cell_lane) cN[(long)seq * H + unit] = c;
+    if (cell_lane) cN[(long)seq * H + unit] = c * (1.0f / QS_K2);
 }
 
 }  // namespace lh
