@@ -10,11 +10,11 @@
 //      (unit u, slice s) keeps the 16-wide k slice s of the unit's four gate rows of W_hh (64 fp32 registers), reads its
 //      16 values of h_{t-1} from LDS (4 broadcast reads instead of the 8 of a half row) and does the 64 FMAs as 32 packed
 //      ones (v_pk_fma_f32 on whole register pairs: the safe form, build.py).  The four partial sums per gate are then
-//      REDUCE-SCATTERED over the quad with DPP quad permutes (lane s ends up with the full sum of gate s: 6 selects + 3
-//      adds, against 12 adds for an all-reduce), so every lane evaluates ONE gate non-linearity (2 transcendentals per
-//      lane and step instead of 8 on one lane in eight), and two more quad permutes bring i*g and o to the lane that holds
-//      the cell state.  4 transcendental + ~70 other instructions per step on an otherwise empty SIMD, one barrier:
-//      0.49 -> ~0.3 us per step (profiles/r03k_*).
+//      REDUCE-SCATTERED over the quad with DPP quad permutes (the gate slots of a lane are XOR-rotated by its slice
+//      index, so lane s ends up with the full sum of gate s after three DPP adds, against 12 adds for an all-reduce),
+//      so every lane evaluates ONE gate non-linearity (2 transcendentals per lane and step instead of 8 on one lane in
+//      eight), and two more quad permutes bring i*g and o to the lane that holds the cell state.  4 transcendental + ~70 other instructions per step on an otherwise empty SIMD, one barrier:
+//      0.49 -> 0.36-0.38 us per step (profiles/r03k_*).
 // Reference: tfgridnet_causal.py:505-512 (intra_norm + intra_rnn); output in the unfused layout [rows][128] consumed
 // by lh_linear_res.
 #include "lh_split.h"
