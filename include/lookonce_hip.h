@@ -222,6 +222,10 @@ int lh_local_attn(const void* q, const void* kx, const void* vx, float* merged, 
  * (hi + lo, i.e. exactly the values the attention kernel used). */
 int lh_ring_pack(const float* k_buf, const float* v_buf, void* kx, void* vx, int B, int T, lh_stream_t stream);
 int lh_ring_unpack(const void* kx, const void* vx, float* k_buf, float* v_buf, int B, int T, lh_stream_t stream);
+/* Streaming ring slot counter (lh_qkv_proj_ln's ring_pos): *ring_pos = (*ring_pos + 1) mod modulo, on the device and in
+ * stream order — one node of the captured per-chunk graph (the reference has no counterpart: it shifts K_buf / V_buf by
+ * one row per chunk, tfgridnet_causal.py:553-562).  modulo in [1, 2^30]. */
+int lh_ring_advance(int* ring_pos, int modulo, lh_stream_t stream);
 
 /* A.3.6  attn_concat_proj: Linear(64->64)+PReLU, joint LayerNorm over (f,c), residual; optional speaker gain.
  * Replaces tfgridnet_causal.py:583-588 and, when gain != NULL, the `batch = batch * embed` applied to the

@@ -11,7 +11,7 @@ from ctypes import c_int, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _P, _I = c_void_p, c_int
 # name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
@@ -32,6 +32,7 @@ SIGNATURES = {
     "lh_local_attn": [_P] * 4 + [_I, _I, _P],
     "lh_ring_pack": [_P] * 4 + [_I, _I, _P],
     "lh_ring_unpack": [_P] * 4 + [_I, _I, _P],
+    "lh_ring_advance": [_P, _I, _P],
     "lh_proj_ln_res": [_P] * 9 + [_I, _I, _P],
     "lh_deconv_istft": [_P] * 9 + [_I, _I, _P],
     "lh_emb_frontend": [_P] * 9 + [_I, _I, _I, _P],

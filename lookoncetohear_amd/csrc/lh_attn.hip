@@ -391,6 +391,19 @@ extern "C" int lh_ring_pack(const float* k_buf, const float* v_buf, void* kx, vo
     return check_launch();
 }
 
+namespace lh {
+__global__ void k_ring_advance(int* pos, int modulo) {
+    const int p = *pos + 1;
+    *pos = p >= modulo ? p - modulo : p;
+}
+}  // namespace lh
+
+extern "C" int lh_ring_advance(int* ring_pos, int modulo, lh_stream_t stream) {
+    if (!ring_pos || modulo < 1 || modulo > (1 << 30)) return LH_ERR_ARG;
+    hipLaunchKernelGGL(lh::k_ring_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, ring_pos, modulo);
+    return lh::check_launch();
+}
+
 extern "C" int lh_ring_unpack(const void* kx, const void* vx, float* k_buf, float* v_buf, int B, int T,
                               lh_stream_t stream) {
     using namespace lh;

@@ -591,8 +591,9 @@ class Streamer:
             self.net._stream_chunk(self.chunk, self.gain, self.sets[k], self.sets[k ^ 1], self.rings, self.pos, self.out,
                                    self._pk, self._ws)
             # ring slot counter, kept in [0, window): an ever-growing int32 would go negative after 2^31 chunks and C's
-            # `%` would then index before the ring
-            self.pos.add_(1).remainder_(self.net.local_atten_len)
+            # `%` would then index before the ring.  One 1-thread kernel (two torch elementwise launches cost 9 us of the chunk)
+            st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+            self.net._lib(self.pos).call("lh_ring_advance", self.pos.data_ptr(), self.net.local_atten_len, st)
 
     def reset(self):
         for st in self.sets:

@@ -424,3 +424,15 @@ def test_inter_xp_shortest_sequences(emu_net):
             assert torch.isfinite(a).all() and (a - b).abs().max() < 2e-6, T
         if T == 1:
             assert all(torch.equal(a, b) for a, b in zip(*res))
+
+
+def test_ring_advance_wraps(emu_net):
+    """lh_ring_advance: the streaming ring slot counter stays in [0, modulo); bad arguments are refused."""
+    import ctypes
+    lib = emu_net._lib_override
+    pos = torch.tensor([48], dtype=torch.int32)
+    for want in (49, 0, 1):
+        lib.call("lh_ring_advance", pos.data_ptr(), 50, 0)
+        assert pos.item() == want
+    assert lib.raw("lh_ring_advance")(ctypes.c_void_p(pos.data_ptr()), 0, None) == 1          # LH_ERR_ARG
+    assert lib.raw("lh_ring_advance")(None, 50, None) == 1
