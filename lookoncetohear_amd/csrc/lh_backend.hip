@@ -27,7 +27,11 @@ constexpr int BE_NLD = (NF * 16 + BE_NT - 1) / BE_NT;   // float4 per thread and
 constexpr int BE_RING = 4;                // input frames in flight per workgroup
 #if defined(LH_PROBE_TRACE)              // timing probe build only (scripts/probe_trace.py --backend): stamps of workgroup 3, tile 2 of its run
 __device__ unsigned long long lh_be_trace_buf[32];
+#if defined(LH_PROBE_TRACE_T1)           // streaming shape (B = 1, T = 1): the only workgroup, its only tile; 20 / 21 = kernel entry / prologue done
+#define BE_STAMP(k) do { if (blockIdx.x == 0 && tid == 0) lh_be_trace_buf[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define BE_STAMP(k) do { if (blockIdx.x == 3 && tid == 0 && tk == k0_ + 2) lh_be_trace_buf[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define BE_STAMP(k) do { } while (0)
 #endif
@@ -57,6 +61,9 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     // the synthesis filterbank tiles 2w, 2w+1 (of 12; 112 registers) are fetched from L2 once per tile, right before
     // they are used — the registers hold the frame prefetch ring while the frames stream
     __shared__ __attribute__((aligned(16))) _Float16 wds[3 * 2 * 64 * 16];
+#if defined(LH_PROBE_TRACE_T1)
+    { const int tk = 0, k0_ = 0; (void)tk; (void)k0_; BE_STAMP(20); }
+#endif
     for (int i = tid; i < 3 * 2 * 64 * 2; i += BE_NT)
         *reinterpret_cast<f16x8*>(&wds[i * 8]) = *reinterpret_cast<const f16x8*>(&wd_pk[i * 8]);
     const bool synth = wave < 6;
@@ -66,14 +73,34 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
 
     // rows / k-padding of the A images that are never written only feed dropped outputs or multiply zero weights,
     // but must be finite
-    for (int i = tid; i < 2 * FR_A; i += BE_NT) { ahi[i] = (_Float16)0.f; alo[i] = (_Float16)0.f; }
-    for (int i = tid; i < NSRC * BE_SA; i += BE_NT) { sxh[i] = (_Float16)0.f; sxl[i] = (_Float16)0.f; }
-    for (int i = tid; i < 4 * 2 * BE_PP; i += BE_NT) pring[i / (2 * BE_PP)][((i / BE_PP) & 1) * (NF + 1)][i % BE_PP] = 0.f;
+    static_assert((2 * FR_A) % 8 == 0 && (NSRC * BE_SA) % 8 == 0, "16-byte zero fill");
+    const f16x8 z8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < 2 * FR_A / 8; i += BE_NT) {
+        *reinterpret_cast<f16x8*>(&ahi[i * 8]) = z8;
+        *reinterpret_cast<f16x8*>(&alo[i * 8]) = z8;
+    }
+    for (int i = tid; i < NSRC * BE_SA / 8; i += BE_NT) {
+        *reinterpret_cast<f16x8*>(&sxh[i * 8]) = z8;
+        *reinterpret_cast<f16x8*>(&sxl[i * 8]) = z8;
+    }
+    auto zero_guards = [&]() {                // rows 0 and 98 of the four partial-product slots
+        for (int i = tid; i < 4 * 2 * BE_PP; i += BE_NT) pring[i / (2 * BE_PP)][((i / BE_PP) & 1) * (NF + 1)][i % BE_PP] = 0.f;
+    };
+    zero_guards();
+    // The carried conv halo is stored channel-major ([B][64][2][97], the reference's state layout), the frames bin-major
+    // ([97][64]): both directions of that transpose go through LDS so that both global sides stay coalesced (the 4-byte
+    // strided loads of the two halo frames cost 11.6 k cycles of a 61 k-cycle streaming call, the element-wise state copy
+    // ~18 k: profiles/r03m_backend_t1.txt).  The buffer lives in the partial-product ring while that is empty / dead.
+    static_assert(2 * C * NF <= 4 * (NF + 2) * BE_PP, "transpose buffer must fit in pring");
+    float* const tbuf = &pring[0][0][0];
 
     // A workgroup walks a RUN of consecutive tiles of one utterance: only the run's first tile pays the 3-frame halo
     // (re-multiplying frames t0-3 .. t0-1); later tiles find the partial products of frames t0-2, t0-1 still in the ring
     // and take Sx[0] (= the spectrum of frame t0-1) from the previous tile's row 15.  At 42 tiles per 5 s clip the halo
     // was 20 % extra frames (PMC: 1.42x the algorithmic bytes); 8 runs per utterance at B = 32 make it 4 %.
+#if defined(LH_PROBE_TRACE_T1)
+    { const int tk = 0, k0_ = 0; (void)tk; (void)k0_; BE_STAMP(21); }
+#endif
     const int tiles_per_b = (T + BE_TT - 1) / BE_TT;
     const int n_runs = B * runs_per_b;
     const long L = (long)HOP * T;
@@ -127,18 +154,6 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
 
         // input frames t0-3 .. t0+nt_out-1 ; after frame fr has been multiplied, output frame td = fr is complete
         float4 stg[BE_RING][BE_NLD];
-        auto load_frame = [&](int fr, float4 (&dst)[BE_NLD]) {
-#pragma unroll
-            for (int i = 0; i < BE_NLD; ++i) {
-                const int e = min(tv + BE_NT * i, NF * 16 - 1), f = e >> 4, c4 = e & 15;
-                if (fr >= 0) {
-                    dst[i] = *reinterpret_cast<const float4*>(&y[(((long)b * T + fr) * NF + f) * C + c4 * 4]);
-                } else {                              // carried halo frames, layout [B][64][2][97]
-                    const float* d0 = &dbuf_in[(((long)b * C + c4 * 4) * 2 + (fr + 2)) * NF + f];
-                    dst[i] = make_float4(d0[0], d0[2 * NF], d0[4 * NF], d0[6 * NF]);
-                }
-            }
-        };
         // fr >= 0: a frame of y.  Per-thread element offsets once per tile, the frame's base is wave-uniform: the load issue
         // of a frame pair took 1300 cycles when every float4 recomputed its 64-bit index
         unsigned eoff[BE_NLD];
@@ -157,10 +172,10 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
         if (fr_first >= 0) {                          // no carried halo frame in the first ring turn: four straight loads
 #pragma unroll
             for (int u = 0; u < BE_RING; ++u) load_frame_y(min(fr_first + u, T - 1), stg[u]);
-        } else {
+        } else {                                      // (the carried halo frames -2, -1 are staged from the state below)
 #pragma unroll
             for (int u = 0; u < BE_RING; ++u)
-                if (fr_first + u < fr_end) load_frame(fr_first + u, stg[u]);
+                if (fr_first + u >= 0 && fr_first + u < fr_end) load_frame_y(fr_first + u, stg[u]);
         }
         BE_STAMP(1);
         for (int fbase = fr_first; fbase < fr_end; fbase += BE_RING) {
@@ -173,12 +188,33 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             const bool tr_it = fbase == fr_first + BE_RING && u == 0;      // probe only
             if (tr_it) BE_STAMP(11);
             // stage the frames into the two A images, refill their ring slots
+            if (fr < 0) {
+                // frames -2, -1 = rows 0, 1 of the carried halo [c][2][f] (first pair of a clip's first tile): a flat coalesced
+                // copy into the transpose buffer, then rows of four channels like any other frame
+                for (int i = tid; i < 2 * C * NF; i += BE_NT) tbuf[i] = dbuf_in[(long)b * 2 * C * NF + i];
+                __syncthreads();
 #pragma unroll
-            for (int i = 0; i < BE_NLD; ++i) {
-                const int e = tv + BE_NT * i;
-                if (e < NF * 16) {
-                    store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[u][i]);
-                    if (two) store_split4<FR_RP>(ahi + FR_A, alo + FR_A, e >> 4, (e & 15) * 4, stg[u + 1][i]);
+                for (int i = 0; i < BE_NLD; ++i) {
+                    const int e = tv + BE_NT * i;
+                    if (e < NF * 16) {
+                        const int f = e >> 4, c0 = (e & 15) * 4;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            store_split4<FR_RP>(ahi + q * FR_A, alo + q * FR_A, f, c0,
+                                                make_float4(tbuf[((c0 + 0) * 2 + q) * NF + f], tbuf[((c0 + 1) * 2 + q) * NF + f],
+                                                            tbuf[((c0 + 2) * 2 + q) * NF + f], tbuf[((c0 + 3) * 2 + q) * NF + f]));
+                    }
+                }
+                __syncthreads();
+                zero_guards();                        // the buffer ran over guard rows; the products below write rows 1..97 only
+            } else {
+#pragma unroll
+                for (int i = 0; i < BE_NLD; ++i) {
+                    const int e = tv + BE_NT * i;
+                    if (e < NF * 16) {
+                        store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[u][i]);
+                        if (two) store_split4<FR_RP>(ahi + FR_A, alo + FR_A, e >> 4, (e & 15) * 4, stg[u + 1][i]);
+                    }
                 }
             }
             __syncthreads();
@@ -274,15 +310,27 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
         __syncthreads();
         BE_STAMP(8);
 
-        // new carried conv halo (last tile only)
+        // new carried conv halo (last tile only): frames T-2, T-1 as [c][2][f]; a frame of y is transposed through LDS
         if (t0 + nt_out == T) {
-            for (int i = tid; i < 2 * NF * C; i += BE_NT) {
-                const int c = i % C, f = (i / C) % NF, r = i / (C * NF);
-                const int fr = T - 2 + r;
-                const float v = fr >= 0 ? y[(((long)b * T + fr) * NF + f) * C + c]
-                                        : dbuf_in[(((long)b * C + c) * 2 + (fr + 2)) * NF + f];
-                dbuf_out[(((long)b * C + c) * 2 + r) * NF + f] = v;
+            for (int r = 0; r < 2; ++r) {
+                const int fr = T - 2 + r;             // workgroup-uniform
+                if (fr >= 0) {
+                    const float* src = y + ((long)b * T + fr) * NF * C;
+                    for (int i = tid; i < NF * C; i += BE_NT) tbuf[(i & (C - 1)) * NF + (i >> 6)] = src[i];
+                    __syncthreads();
+                    for (int i = tid; i < NF * C; i += BE_NT) {
+                        const int c = i / NF, f = i - c * NF;
+                        dbuf_out[(((long)b * C + c) * 2 + r) * NF + f] = tbuf[i];
+                    }
+                    __syncthreads();
+                } else {                              // still a carried frame: same layout on both sides
+                    for (int i = tid; i < NF * C; i += BE_NT) {
+                        const int c = i / NF, f = i - c * NF;
+                        dbuf_out[(((long)b * C + c) * 2 + r) * NF + f] = dbuf_in[(((long)b * C + c) * 2 + (fr + 2)) * NF + f];
+                    }
+                }
             }
+            zero_guards();                            // (ordered before the next tile's gather by the barriers in between)
         }
 
         // synthesis: fr[jd][s][n] = sum_k Sx[jd][s][k] Wdec[k][n]; row tile = the 16 frames of a source, waves 0..5
