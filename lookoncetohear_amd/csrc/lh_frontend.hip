@@ -49,7 +49,11 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
     load_w<2>(wc_pk, cnt, lane, wch, wcl);
     const float cbias = bc[cnt * 16 + l15];
 
-    for (int i = tid; i < (NF + 2) * FE_SP; i += FE_NTH) { sth[i] = (_Float16)0.f; stl[i] = (_Float16)0.f; }   // pad rows / columns
+    static_assert(((NF + 2) * FE_SP) % 4 == 0, "8-byte zero fill");
+    for (int i = tid; i < (NF + 2) * FE_SP / 4; i += FE_NTH) {          // pad rows / columns
+        *reinterpret_cast<f16x4*>(&sth[i * 4]) = f16x4{0, 0, 0, 0};
+        *reinterpret_cast<f16x4*>(&stl[i * 4]) = f16x4{0, 0, 0, 0};
+    }
 
     const int tiles_per_b = (T + FE_TT - 1) / FE_TT;
     for (int tile = blockIdx.x; tile < B * tiles_per_b; tile += gridDim.x) {

@@ -147,7 +147,11 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
     quad_load_w(whh + (long)dir * IS_GP * H, unit, qs, wr);
 
     // ---- LayerNorm over the 64 channels of every (frame, f) row (affine folded into the weights), split to fp16 hi/lo
-    for (int i = tid; i < FR_A; i += IS_NT) { ahi[i] = (_Float16)0.f; alo[i] = (_Float16)0.f; }
+    static_assert(FR_A % 8 == 0, "16-byte zero fill");
+    for (int i = tid; i < FR_A / 8; i += IS_NT) {
+        *reinterpret_cast<f16x8*>(&ahi[i * 8]) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        *reinterpret_cast<f16x8*>(&alo[i * 8]) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < IS_NLD; ++i) {
