@@ -39,6 +39,12 @@ NO_SLP = ["-fno-slp-vectorize", "-fno-vectorize"]      # (the loop vectoriser pa
 FILE_FLAGS = {"lh_render.hip": ["-fslp-vectorize", "-fvectorize"]}
 
 
+def is_unsafe_packed_fp32(asm_line: str) -> bool:
+    """One line of llvm-objdump output: a packed fp32 add / mul / fma whose op_sel crosses the halves of src1 and only src1."""
+    import re
+    return bool(re.search(r"v_pk_(add|mul|fma)_f32", asm_line) and re.search(r"op_sel:\[0,1(,0)?\]", asm_line))
+
+
 def unsafe_packed_fp32(lib_path: str):
     """Disassembles the gfx950 code object inside `lib_path` and returns the packed-fp32 instructions whose op_sel crosses
     the halves of src1 only (see above)."""
@@ -67,10 +73,7 @@ def unsafe_packed_fp32(lib_path: str):
                 r = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True)
                 if "v_mfma" in r.stdout or "v_pk_" in r.stdout:
                     text += r.stdout
-    bad = []
-    for line in text.splitlines():
-        if re.search(r"v_pk_(add|mul|fma)_f32", line) and re.search(r"op_sel:\[0,1(,0)?\]", line):
-            bad.append(line.strip())
+    bad = [line.strip() for line in text.splitlines() if is_unsafe_packed_fp32(line)]
     return bad, text.count("v_pk_fma_f32") + text.count("v_pk_add_f32") + text.count("v_pk_mul_f32"), ("v_mfma" in text)
 
 

@@ -52,7 +52,26 @@ def test_library_has_no_unsafe_packed_fp32():
     bad, n_packed, seen = unsafe_packed_fp32(build_hip())
     assert seen, "could not disassemble the gfx950 code object"
     assert not bad, bad[:3]
-    assert n_packed < 200            # only the direct-form FIR kernel keeps (default-select) packed fp32
+    assert n_packed < 200            # the direct-form FIR kernel and the quad-lane LSTM step keep (default-select) packed fp32
+
+
+def test_isa_guard_classification():
+    """The forms measured safe / unsafe by scripts/ubench/pk_race* (profiles/r03c_packed_fp32_corruption.txt), as llvm-objdump
+    prints them — including the one hipcc formed from two horizontal sums in lh_stream.hip (caught by the guard, round 3)."""
+    from lookoncetohear_amd.build import is_unsafe_packed_fp32 as bad
+    assert bad("v_pk_add_f32 v[74:75], v[76:77], v[76:77] op_sel:[0,1] op_sel_hi:[1,0]// 000000002C80: D3B2504A 0802994C")
+    assert bad("\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0]")
+    assert bad("v_pk_mul_f32 v[8:9], v[2:3], v[4:5] op_sel:[0,1]")
+    for ok in ("v_pk_fma_f32 v[90:91], v[14:15], v[74:75], 0 op_sel_hi:[1,1,0]",
+               "v_pk_fma_f32 v[76:77], v[10:11], v[78:79], v[90:91]",
+               "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]",
+               "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,1]",
+               "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,0,0]",
+               "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]",
+               "v_pk_mul_f32 v[0:1], v[2:3], v[4:5] neg_lo:[0,1] neg_hi:[0,1]",
+               "v_pk_add_f16 v0, v1, v2 op_sel:[0,1]",                      # packed fp16: not the affected unit
+               "v_fma_f32 v0, v1, v2, v3"):
+        assert not bad(ok), ok
 
 
 def test_missing_library_fails_loudly(tmp_path):
