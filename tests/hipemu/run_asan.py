@@ -6,7 +6,9 @@ Builds tests/hipemu/_build/liblookonce_emu_asan.so (the unmodified kernel source
 tests/test_emu_kernels.py against it with the ASan runtime preloaded into the interpreter: every global-memory access of a kernel
 is checked against the torch allocation it points into, every LDS access (`__shared__` = static array here) against its array.
 Round 3: the 21 emulator tests are clean; a deliberately short state buffer handed to lh_ring_unpack is reported as
-heap-buffer-overflow in k_ring_unpack (negative control).  Not part of `pytest -m "not gpu"` (needs LD_PRELOAD)."""
+heap-buffer-overflow in k_ring_unpack (negative control).  `--ubsan` builds with -fsanitize=undefined,alignment instead
+(misaligned vector accesses, signed overflow, out-of-range shifts): also clean.  Not part of `pytest -m "not gpu"` (needs
+LD_PRELOAD)."""
 import glob
 import os
 import subprocess
@@ -28,14 +30,24 @@ sys.exit(pytest.main(["-x", "-q", os.path.join(%(root)r, "tests", "test_emu_kern
 
 def main():
     from tests.hipemu.build_emu import build_emu
-    lib = os.path.join(HERE, "_build", "liblookonce_emu_asan.so")
-    build_emu(force=False, extra_flags=["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan"], out=lib)
-    rt = sorted(glob.glob("/opt/rocm*/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    args = sys.argv[1:]
+    ubsan = "--ubsan" in args
+    args = [a for a in args if a != "--ubsan"]
+    if ubsan:
+        lib = os.path.join(HERE, "_build", "liblookonce_emu_ubsan.so")
+        flags = ["-fsanitize=undefined,alignment", "-fno-sanitize=vptr,function", "-fno-omit-frame-pointer", "-shared-libsan"]
+        rt_name, env_extra = "libclang_rt.ubsan_standalone-x86_64.so", {"UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"}
+    else:
+        lib = os.path.join(HERE, "_build", "liblookonce_emu_asan.so")
+        flags = ["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan"]
+        rt_name = "libclang_rt.asan-x86_64.so"
+        env_extra = {"ASAN_OPTIONS": "detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1:verify_asan_link_order=0"}
+    build_emu(force=False, extra_flags=flags, out=lib)
+    rt = sorted(glob.glob("/opt/rocm*/lib/llvm/lib/clang/*/lib/linux/" + rt_name))
     if not rt:
-        sys.exit("no libclang_rt.asan-x86_64.so under /opt/rocm")
-    env = dict(os.environ, LD_PRELOAD=rt[-1],
-               ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1:verify_asan_link_order=0")
-    return subprocess.call([sys.executable, "-c", CHILD % {"root": ROOT, "lib": lib}] + sys.argv[1:], env=env)
+        sys.exit("no %s under /opt/rocm" % rt_name)
+    env = dict(os.environ, LD_PRELOAD=rt[-1], **env_extra)
+    return subprocess.call([sys.executable, "-c", CHILD % {"root": ROOT, "lib": lib}] + args, env=env)
 
 
 if __name__ == "__main__":
