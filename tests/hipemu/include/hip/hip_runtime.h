@@ -26,7 +26,13 @@ using std::max;
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#if defined(HIPEMU_RACE)
+// LDS race detector build (tests/hipemu/run_race.py): every `__shared__` array goes into one named section so that the
+// access hooks below can tell LDS from everything else by address
+#define __shared__ static __attribute__((section("hipemu_lds")))
+#else
 #define __shared__ static
+#endif
 #define __launch_bounds__(...)
 #define __constant__ static
 
@@ -106,6 +112,8 @@ struct Globals {
     std::function<void()>* body = nullptr;
     char* stacks = nullptr;
     size_t nstacks = 0;
+    uint64_t epoch = 1;            // race detector: +1 at every completed workgroup barrier and at every workgroup start
+    const char* kernel = "";       // name of the running kernel (hipLaunchKernelGGL's first argument)
 };
 inline Globals& G() { static Globals g; return g; }
 constexpr size_t kStack = 128 * 1024;
@@ -123,7 +131,7 @@ inline void block_barrier() {
     Globals& g = G();
     BlockState& b = g.blk;
     unsigned my = b.gen;
-    if (++b.arrived >= b.alive) { b.arrived = 0; b.gen++; return; }
+    if (++b.arrived >= b.alive) { b.arrived = 0; b.gen++; g.epoch++; return; }
     while (b.gen == my) yield();
 }
 
@@ -144,7 +152,7 @@ inline void wave_barrier() {
     BlockState& b = g.blk;
     WaveState& w = b.waves[me->lin >> 6];
     b.alive--; w.alive--;
-    if (b.alive && b.arrived >= b.alive) { b.arrived = 0; b.gen++; }
+    if (b.alive && b.arrived >= b.alive) { b.arrived = 0; b.gen++; g.epoch++; }
     if (w.alive && w.arrived >= w.alive) { w.arrived = 0; w.gen++; }
     if (me->next == me) {                       // last fiber of the block: back to the scheduler
         hipemu_switch(&me->sp, g.sched_sp);
@@ -175,6 +183,7 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
     g.dyn_smem = (char*)(((uintptr_t)dyn.data() + 63) & ~(uintptr_t)63);
     for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
         g.bid = dim3(bx, by, bz);
+        g.epoch++;
         memset(g.dyn_smem, 0xFF, shmem);       // poison dynamic LDS with NaNs between workgroups
         g.blk = BlockState();
         g.blk.alive = nthr;
@@ -273,6 +282,109 @@ inline v4f mfma_16x16x32_f16(v8h a, v8h b, v4f c) {
 
 }  // namespace hipemu
 
+
+#if defined(HIPEMU_RACE)
+// ---- LDS race detector -------------------------------------------------------------------------------
+// The kernels are compiled with -fsanitize=thread but WITHOUT the ThreadSanitizer runtime: the instrumentation's
+// __tsan_readN / __tsan_writeN calls land in the hooks below.  Model: two accesses to the same LDS byte by DIFFERENT
+// WAVES of a workgroup, at least one of them a write, with no workgroup barrier between them, are a race (hardware gives
+// no order between waves except barriers; inside a wave the lanes run in lockstep and LDS operations are in order).
+// Epoch = number of completed barriers: a conflict needs both accesses in the same epoch.
+#include <dlfcn.h>
+extern "C" char __start_hipemu_lds[] __attribute__((weak));
+extern "C" char __stop_hipemu_lds[] __attribute__((weak));
+namespace hipemu {
+struct RaceCell { uint64_t wepoch = 0, repoch = 0; uint16_t wwave = 0, rwave = 0; uint8_t rmulti = 0; };
+struct RaceState {
+    std::vector<RaceCell> cells;
+    uintptr_t lo = 0, len = 0;
+    unsigned long reports = 0;
+    std::vector<uint64_t> seen;          // (pc, kind) pairs already printed
+    __attribute__((no_sanitize("thread"))) RaceState() {
+        lo = (uintptr_t)__start_hipemu_lds;
+        len = (uintptr_t)__stop_hipemu_lds - lo;
+        cells.resize(len);
+    }
+};
+__attribute__((no_sanitize("thread"))) inline RaceState& R() { static RaceState r; return r; }
+inline bool& race_busy() { static bool b = false; return b; }      // the hooks call instrumented library code (vector, stdio)
+__attribute__((no_sanitize("thread"))) inline void race_report(const char* kind, uintptr_t addr, unsigned other_wave, void* pc) {
+    RaceState& r = R();
+    r.reports++;
+    const uint64_t key = (uint64_t)(uintptr_t)pc * 4 + (kind[0] == 'R' ? 0 : kind[0] == 'W' && kind[1] == 'A' && kind[2] == 'W' ? 1 : 2);
+    for (uint64_t k : r.seen) if (k == key) return;
+    r.seen.push_back(key);
+    Dl_info di;
+    uintptr_t off = (uintptr_t)pc;
+    if (dladdr(pc, &di) && di.dli_fbase) off -= (uintptr_t)di.dli_fbase;
+    Globals& g = G();
+    fprintf(stderr, "hipemu RACE %s in %s: LDS byte +%lu, thread %u (wave %u) vs wave %u, no barrier between; block (%u,%u) pc +0x%lx\n",
+            kind, g.kernel, (unsigned long)(addr - r.lo), g.cur->lin, g.cur->lin >> 6, other_wave, g.bid.x, g.bid.y, (unsigned long)off);
+}
+__attribute__((no_sanitize("thread"))) inline void race_access(const void* p, unsigned n, bool write, void* pc) {
+    bool& busy = race_busy();
+    if (busy) return;
+    busy = true;
+    struct Unbusy { bool& b; ~Unbusy() { b = false; } } unbusy{busy};
+    RaceState& r = R();
+    const uintptr_t a = (uintptr_t)p;
+    if (a - r.lo >= r.len) return;
+    Globals& g = G();
+    if (!g.cur) return;
+    const uint16_t w = (uint16_t)(g.cur->lin >> 6);
+    const uint64_t e = g.epoch;
+    for (unsigned i = 0; i < n && a + i - r.lo < r.len; ++i) {
+        RaceCell& c = r.cells[a + i - r.lo];
+        if (write) {
+            if (c.wepoch == e && c.wwave != w) { race_report("WAW", a + i, c.wwave, pc); }
+            if (c.repoch == e && (c.rwave != w || c.rmulti)) { race_report("WAR", a + i, c.rwave, pc); }
+            c.wepoch = e; c.wwave = w;
+        } else {
+            if (c.wepoch == e && c.wwave != w) { race_report("RAW", a + i, c.wwave, pc); }
+            if (c.repoch != e) { c.repoch = e; c.rwave = w; c.rmulti = 0; }
+            else if (c.rwave != w) c.rmulti = 1;
+        }
+    }
+}
+}  // namespace hipemu
+#define HIPEMU_HOOK extern "C" __attribute__((weak, no_sanitize("thread"), noinline))
+HIPEMU_HOOK void __tsan_init() {}
+HIPEMU_HOOK void __tsan_func_entry(void*) {}
+HIPEMU_HOOK void __tsan_func_exit() {}
+HIPEMU_HOOK void __tsan_vptr_update(void**, void*) {}
+HIPEMU_HOOK void __tsan_vptr_read(void**) {}
+#define HIPEMU_RW(N) \
+    HIPEMU_HOOK void __tsan_read##N(void* p) { hipemu::race_access(p, N, false, __builtin_return_address(0)); } \
+    HIPEMU_HOOK void __tsan_write##N(void* p) { hipemu::race_access(p, N, true, __builtin_return_address(0)); } \
+    HIPEMU_HOOK void __tsan_unaligned_read##N(void* p) { hipemu::race_access(p, N, false, __builtin_return_address(0)); } \
+    HIPEMU_HOOK void __tsan_unaligned_write##N(void* p) { hipemu::race_access(p, N, true, __builtin_return_address(0)); } \
+    HIPEMU_HOOK void __tsan_read##N##_pc(void* p, void*) { hipemu::race_access(p, N, false, __builtin_return_address(0)); } \
+    HIPEMU_HOOK void __tsan_write##N##_pc(void* p, void*) { hipemu::race_access(p, N, true, __builtin_return_address(0)); }
+HIPEMU_RW(1) HIPEMU_RW(2) HIPEMU_RW(4) HIPEMU_RW(8) HIPEMU_RW(16)
+HIPEMU_HOOK void __tsan_read_range(void* p, unsigned long n) { hipemu::race_access(p, (unsigned)n, false, __builtin_return_address(0)); }
+HIPEMU_HOOK void __tsan_write_range(void* p, unsigned long n) { hipemu::race_access(p, (unsigned)n, true, __builtin_return_address(0)); }
+HIPEMU_HOOK void* __tsan_memcpy(void* d, const void* s, unsigned long n) {
+    hipemu::race_access(s, (unsigned)n, false, __builtin_return_address(0));
+    hipemu::race_access(d, (unsigned)n, true, __builtin_return_address(0));
+    return __builtin_memcpy(d, s, n);
+}
+HIPEMU_HOOK void* __tsan_memmove(void* d, const void* s, unsigned long n) {
+    hipemu::race_access(s, (unsigned)n, false, __builtin_return_address(0));
+    hipemu::race_access(d, (unsigned)n, true, __builtin_return_address(0));
+    return __builtin_memmove(d, s, n);
+}
+HIPEMU_HOOK void* __tsan_memset(void* d, int v, unsigned long n) {
+    hipemu::race_access(d, (unsigned)n, true, __builtin_return_address(0));
+    return __builtin_memset(d, v, n);
+}
+// (guard variables of function-local statics: the only atomics the instrumented sources contain)
+// (plain volatile accesses: an __atomic builtin in here is itself rewritten into a call of this hook; everything runs on one
+//  OS thread, and x86 loads / stores are acquire / release)
+HIPEMU_HOOK unsigned char __tsan_atomic8_load(const volatile unsigned char* a, int) { return *a; }
+HIPEMU_HOOK void __tsan_atomic8_store(volatile unsigned char* a, unsigned char v, int) { *a = v; }
+extern "C" __attribute__((weak)) unsigned long hipemu_race_reports() { return hipemu::R().reports; }
+#endif
+
 // x86-64 SysV context switch: save callee-saved registers, swap stack pointers.
 __asm__(R"(
 .text
@@ -305,7 +417,7 @@ hipemu_switch:
 
 #define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)hipemu::G().dyn_smem;
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    hipemu::launch((grid), (block), (shmem), [&]() { kern(__VA_ARGS__); })
+    (hipemu::G().kernel = #kern, hipemu::launch((grid), (block), (shmem), [&]() { kern(__VA_ARGS__); }))
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
 template <class T> static inline T __shfl(T v, int src, int width = 64) {
