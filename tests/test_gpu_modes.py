@@ -290,6 +290,39 @@ def test_two_forwards_on_two_streams_are_bit_identical(oracle_cfg_sd):
     torch.cuda.empty_cache()
 
 
+def test_batch1_forward_next_to_a_batched_forward_is_bit_identical(oracle_cfg_sd):
+    """The quad-lane LSTM step of the batch-1 path (`k_inter_matvec`, lh_stream.hip) runs its mat-vec on v_pk_fma_f32 — the
+    packed forms the ISA guard allows.  Run it on one stream while the matrix-heavy batch-16 forward (the kernels next to which
+    the unsafe packed form lost lanes 48..63) runs on another: the batch-1 output must equal the same forward run alone."""
+    _, sd = oracle_cfg_sd
+    nets2 = [_make(sd), _make(sd)]
+    for n in nets2:
+        n.range_check = False
+    d = synth.batch(list(range(70, 86)), 80000)
+    big = (d["mixture"].to(DEV), d["embedding_gt"].to(DEV))
+    one = (d["mixture"][3:4].contiguous().to(DEV), d["embedding_gt"][3:4].contiguous().to(DEV))
+    alone = nets2[1](*one)
+    big_alone = nets2[0](*big)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    for rep in range(3):
+        cur = torch.cuda.current_stream(DEV)
+        for s_ in streams:
+            s_.wait_stream(cur)
+        with torch.cuda.stream(streams[0]):
+            for _ in range(2):
+                yb = nets2[0](*big)
+        with torch.cuda.stream(streams[1]):
+            for _ in range(6):                      # ~1.6 ms each against ~4 ms of the batched forward
+                y1 = nets2[1](*one)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, alone), (rep, float((y1 - alone).abs().max()))
+        assert torch.equal(yb, big_alone), (rep, float((yb - big_alone).abs().max()))
+    for n in nets2:
+        n._ws.clear()
+    torch.cuda.empty_cache()
+
+
 def test_packed_blob_drives_the_c_abi_without_net(oracle_cfg_sd):
     """the packed weight blob (checkpoint.export_packed / import_packed, include/lookonce_weights.h)
     is enough to run the separator through the C ABI — no `Net` instance: tensors of the blob are uploaded as they
