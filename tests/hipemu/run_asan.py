@@ -24,7 +24,7 @@ sys.path.insert(0, %(root)r)
 import tests.hipemu.build_emu as be
 be.build_emu = lambda *a, **k: %(lib)r          # the fixtures load the sanitised library
 import pytest
-sys.exit(pytest.main(["-x", "-q", os.path.join(%(root)r, "tests", "test_emu_kernels.py"), "-p", "no:cacheprovider"] + sys.argv[1:]))
+sys.exit(pytest.main(["-x", "-q", os.path.join(%(root)r, "tests", "test_emu_kernels.py"), os.path.join(%(root)r, "tests", "test_render.py"), "-m", "not gpu", "-p", "no:cacheprovider"] + sys.argv[1:]))
 """
 
 

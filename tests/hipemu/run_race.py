@@ -22,7 +22,7 @@ sys.path.insert(0, %(root)r)
 import tests.hipemu.build_emu as be
 be.build_emu = lambda *a, **k: %(lib)r          # the fixtures load the instrumented library
 import pytest
-rc = pytest.main(["-q", os.path.join(%(root)r, "tests", "test_emu_kernels.py"), "-p", "no:cacheprovider"] + sys.argv[1:])
+rc = pytest.main(["-q", os.path.join(%(root)r, "tests", "test_emu_kernels.py"), os.path.join(%(root)r, "tests", "test_render.py"), "-m", "not gpu", "-p", "no:cacheprovider"] + sys.argv[1:])
 import ctypes
 n = ctypes.CDLL(%(lib)r).hipemu_race_reports
 n.restype = ctypes.c_ulong
