@@ -29,27 +29,32 @@ enum {
     LH_ERR_ARG = 1,         /* null pointer / non-positive size */
     LH_ERR_UNSUPPORTED = 2, /* shape constants differ from the compiled configuration */
     LH_ERR_LAUNCH = 3,      /* hipGetLastError() != hipSuccess after the launch */
-    LH_ERR_RANGE = 4        /* lh_range_status only: a non-finite output sample was produced since the last check */
+    LH_ERR_RANGE = 4        /* lh_range_status only: a non-finite output sample was produced since the caller's last check */
 };
 
 /* Range contract of the split-precision ("f16x3") arithmetic.  Operands are carried as fp16 hi + fp16 lo, so every value
- * a kernel SPLITS must satisfy |v| < 65504.  LayerNorm outputs, hidden states, attention rows and weights always do; the
- * un-normalised residual stream (read by lh_qkv_proj_ln, lh_proj_ln_res, lh_deconv_istft, and the waveform / spectrum in
- * lh_stft_conv_in) does only while the network's activations stay below that bound — in EVERY gemm mode, because
- * LH_GEMM_F32 only switches the two recurrences to exact fp32 (the frame kernels are split-precision always).  Beyond the
- * bound hi becomes inf, the frame's products NaN, and the NaN reaches the output waveform; lh_deconv_istft then sets a
- * sticky per-device flag.  (A NaN / inf in the inputs raises the same flag.)
- *   lh_range_status: copies the flag to the host on `stream`, WAITS for the stream, clears the flag; LH_OK, or
+ * a kernel SPLITS must satisfy |v| < 65504 AFTER the kernel's own scaling.  LayerNorm outputs, hidden states, attention
+ * rows and weights always do.  The kernels that read un-normalised data (the waveform in lh_stft_conv_in, the residual
+ * stream in lh_qkv_proj_ln and lh_deconv_istft) multiply each row / tile by an exact power of two chosen from its own
+ * maximum before the split and undo it after the fp32 accumulation (since ABI 12), so any finite fp32 input whose exact
+ * result is finite in fp32 is computed to the same ~22 bits relative to the row maximum — the reference's behaviour
+ * (plain fp32, tfgridnet_causal.py:188-283).  What remains is a GUARD for non-finite data: lh_deconv_istft stores 0 (not
+ * NaN / inf) for a non-finite output sample and raises a CALLER-OWNED flag:
+ *   range_flag       device memory, two 32-bit words, zero-initialised by the caller: [0] = sticky word raised by
+ *                    lh_deconv_istft (NULL = no reporting), [1] = the value the last fetch took out of [0].  Each Net /
+ *                    Streamer / host thread owns its own, so concurrent forwards on one device cannot consume or clear
+ *                    one another's flag (ABI <= 11 kept one word per device).
+ *   lh_range_status: [1] = atomicExch([0], 0) on `stream`, copies [1] to the host, WAITS for the stream; LH_OK, or
  *                    LH_ERR_RANGE when it was set.  The one entry point that synchronises: call it once per forward.
- *   lh_range_flag_copy: asynchronous copy of the flag to `host_pinned` (4 bytes of pinned host memory) on `stream`, no
- *                    wait, no clear — capturable in a HIP graph (the streaming host polls the word one chunk later).
- *   lh_range_flag_clear: asynchronous clear on `stream`.
+ *   lh_range_flag_copy: the same exchange followed by an asynchronous copy of [1] to `host_pinned` (4 bytes of pinned host
+ *                    memory) on `stream`, no wait (the streaming host looks at the word when later chunks arrive).
+ *   lh_range_flag_clear: asynchronous clear of both words on `stream`.
  *   lh_selftest_fp16_subnormal: runs one v_mfma_f32_16x16x32_f16 on fp16-subnormal operands (the un-rescaled lo halves
  *                    rely on the matrix core taking them at full value); LH_OK, or LH_ERR_UNSUPPORTED when they are
  *                    flushed.  Synchronises. */
-int lh_range_status(lh_stream_t stream);
-int lh_range_flag_copy(void* host_pinned, lh_stream_t stream);
-int lh_range_flag_clear(lh_stream_t stream);
+int lh_range_status(unsigned* range_flag, lh_stream_t stream);
+int lh_range_flag_copy(unsigned* range_flag, void* host_pinned, lh_stream_t stream);
+int lh_range_flag_clear(unsigned* range_flag, lh_stream_t stream);
 int lh_selftest_fp16_subnormal(lh_stream_t stream);
 
 /* Contraction arithmetic of the recurrent kernels (argument `mode`):
@@ -242,11 +247,11 @@ int lh_proj_ln_res(const float* merged, const void* w_pk, const float* bias, con
  *   wdec_pk fp16 hi/lo B image [3 ntiles][2 ksteps][64 lanes][16] of deconv.weight as [(kt,kf,o) 36 -> 48] x [64 c];
  *   bdec [4]; wfb_dec fp16 hi/lo B image [12 ntiles][7 ksteps][64 lanes][16] of dec.filterbank._filters^T
  *   [192 samples] x [194 -> 224 rows]   (weights.py pack_linear_f16x3)
- *   wave_out [B][2][128*T]
+ *   wave_out [B][2][128*T];  range_flag: the caller's two-word flag (range contract above) or NULL
  */
 int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out, const float* istft_buf_in,
                     float* istft_buf_out, const void* wdec_pk, const float* bdec, const void* wfb_dec,
-                    float* wave_out, int B, int T, lh_stream_t stream);
+                    float* wave_out, unsigned* range_flag, int B, int T, lh_stream_t stream);
 
 /* ---- enrollment embedder (reference src/models/tfgridnet_orig/tfgridnet.py:88-127 + espnet2 TF-GridNet trunk) ----
  * Front end, tfgridnet.py:109-117: x / std(x) (unbiased, over samples and mics), STFT(n_fft 128, hop 64, hann, centred

@@ -11,7 +11,7 @@ from ctypes import c_int, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _P, _I = c_void_p, c_int
 # name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
@@ -34,16 +34,16 @@ SIGNATURES = {
     "lh_ring_unpack": [_P] * 4 + [_I, _I, _P],
     "lh_ring_advance": [_P, _I, _P],
     "lh_proj_ln_res": [_P] * 9 + [_I, _I, _P],
-    "lh_deconv_istft": [_P] * 9 + [_I, _I, _P],
+    "lh_deconv_istft": [_P] * 10 + [_I, _I, _P],
     "lh_emb_frontend": [_P] * 9 + [_I, _I, _I, _P],
     "lh_emb_axis": [_P] * 10 + [_I, _I, _I, _P],
     "lh_emb_attn_block": [_P] * 23 + [_I, _I, _P],
     "lh_emb_head": [_P] * 7 + [_I, _I, _P],
     "lh_render_binaural": [_P] * 8 + [_I, _I, _I, _I, _P],
     "lh_metric_sums": [_P] * 8 + [_I, _I, _I, _P],
-    "lh_range_status": [_P],
-    "lh_range_flag_copy": [_P, _P],
-    "lh_range_flag_clear": [_P],
+    "lh_range_status": [_P, _P],
+    "lh_range_flag_copy": [_P, _P, _P],
+    "lh_range_flag_clear": [_P, _P],
     "lh_selftest_fp16_subnormal": [_P],
     "lh_comm_unique_id": [_P],
     "lh_comm_init": [_P, _I, _I, _P],

@@ -37,13 +37,12 @@ __device__ unsigned long long lh_be_trace_buf[32];
 #endif
 
 // grid = persistent (<= 256), block 512
-__device__ unsigned lh_range_flag = 0;        // set when a non-finite output sample is stored (range contract, lookonce_hip.h)
-
 __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict__ y, const float* __restrict__ dbuf_in,
                                                         float* __restrict__ dbuf_out, const float* __restrict__ ibuf_in,
                                                         float* __restrict__ ibuf_out, const _Float16* __restrict__ wd_pk,
                                                         const float* __restrict__ bd, const _Float16* __restrict__ wfb_pk,
-                                                        float* __restrict__ wave_out, int B, int T, int runs_per_b) {
+                                                        float* __restrict__ wave_out, unsigned* __restrict__ range_flag,
+                                                        int B, int T, int runs_per_b) {
     // Two input frames per loop iteration (half the barriers; at one frame the loop was ~80 % stall): two A images, and
     // a partial-product ring of 4 frames (2 being written while the gather still reads the 2 before them).
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * FR_A];                 // A images of two input frames
@@ -61,6 +60,16 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     // the synthesis filterbank tiles 2w, 2w+1 (of 12; 112 registers) are fetched from L2 once per tile, right before
     // they are used — the registers hold the frame prefetch ring while the frames stream
     __shared__ __attribute__((aligned(16))) _Float16 wds[3 * 2 * 64 * 16];
+    // Range-safe splits (pow2_scale, lh_common.h).  The frames are rows of the un-normalised residual stream: each row is
+    // scaled by its own power of two, `rinv[q][row]` undoes it on the partial products.  The spectra are split a second
+    // time (synthesis A image): frame td is scaled by a power of two taken from a BOUND of its magnitude,
+    //     |D[td]| <= max|b| + 3 W1 (M[td] + M[td-1] + M[td-2]),   M[fr] = max |Y[fr]|,  W1 = max_col sum_c |Wd[col][c]|
+    // (data-independent of the products, so no extra barrier); `sinv[jd]` undoes it on the synthesis accumulators.
+    __shared__ __attribute__((aligned(16))) float rinv[2][FR_RP];
+    __shared__ float wmax[2][BE_NT / 64];            // per-wave maxima of the two frames being staged
+    __shared__ float fmaxr[4];                        // M[fr] ring, slot (fr + 4) & 3 like the partial products
+    __shared__ __attribute__((aligned(16))) float sinv[BE_NJ];
+    __shared__ float w1s[48];
 #if defined(LH_PROBE_TRACE_T1)
     { const int tk = 0, k0_ = 0; (void)tk; (void)k0_; BE_STAMP(20); }
 #endif
@@ -70,6 +79,23 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     float bias4[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) bias4[o] = bd[o];
+    const float bmax = fmaxf(fmaxf(fabsf(bias4[0]), fabsf(bias4[1])), fmaxf(fabsf(bias4[2]), fabsf(bias4[3])));
+    if (tid < 2 * FR_RP) rinv[0][tid] = 0.f;
+    if (tid < 4) fmaxr[tid] = 0.f;
+    if (tid < BE_NJ) sinv[tid] = 0.f;
+    __syncthreads();                              // wds complete
+    if (tid < 48) {                               // L1 norm of tap column tid (|hi| + |lo| >= |w|), fragment order
+        float a = 0.f;
+        for (int k = 0; k < C; ++k) {
+            const int idx = (((tid >> 4) * 2 + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (tid & 15)) * 16 + (k & 7);
+            a += fabsf((float)wds[idx]) + fabsf((float)wds[idx + 8]);
+        }
+        w1s[tid] = a;
+    }
+    __syncthreads();
+    float W1 = 0.f;
+    for (int i = 0; i < 48; ++i) W1 = fmaxf(W1, w1s[i]);
+    W1 *= 3.0f;                                   // three frequency taps per frame
 
     // rows / k-padding of the A images that are never written only feed dropped outputs or multiply zero weights,
     // but must be finite
@@ -129,6 +155,19 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
         __syncthreads();
         BE_STAMP(0);
 
+        // one float4 of a frame row (element e: row e >> 4, channels 4 (e & 15) ..) -> A image, scaled by the row's power of
+        // two (the 16 lanes of a row reduce its maximum with DPP; whole rows are in or out of range together); returns the
+        // running maximum of this thread's rows
+        auto stage_row = [&](_Float16* ih, _Float16* il, float* riv, int e, const float4& v, float run) -> float {
+            const float m = group16_max(absmax4(v));
+            float sc, iv;
+            pow2_scale<FR_TE>(m, sc, iv);
+            if (e < NF * 16) {
+                store_split4<FR_RP>(ih, il, e >> 4, (e & 15) * 4, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
+                if ((e & 15) == 0) riv[e >> 4] = iv;
+            }
+            return fmaxf(run, m);
+        };
         // one spectrum value -> row jd of source s's A image
         auto put_sx = [&](int jd, int s, int k, float v) {
             _Float16 h, l;
@@ -139,8 +178,20 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
         };
         // Sx frame 0: the carried spectrum of the previous call (first tile of the clip), the previous tile's last
         // frame (inside a run), or recomputed from the halo frames (first tile of a later run)
-        if (t0 == 0) {
-            for (int i = tid; i < NSRC * NK; i += BE_NT) put_sx(0, i / NK, i % NK, ibuf_in[(long)b * NSRC * NK + i]);
+        if (t0 == 0) {                                // (workgroup-uniform)
+            static_assert(NSRC * NK <= BE_NT, "one carried spectrum value per thread");
+            const float cv = tid < NSRC * NK ? ibuf_in[(long)b * NSRC * NK + tid] : 0.f;
+            const float wm = wave_max(fabsf(cv));
+            if (lane == 0) wmax[0][wave] = wm;
+            __syncthreads();
+            float m = wmax[0][0];
+#pragma unroll
+            for (int w = 1; w < BE_NT / 64; ++w) m = fmaxf(m, wmax[0][w]);
+            float sc, iv;
+            pow2_scale<12>(m, sc, iv);
+            if (tid < NSRC * NK) put_sx(0, tid / NK, tid % NK, cv * sc);
+            if (tid == 0) sinv[0] = iv;
+            __syncthreads();                          // wmax is rewritten by the frame staging
         } else if (cont) {
             for (int i = tid; i < NSRC * NK; i += BE_NT) {
                 const int s = i / NK, k = i % NK;
@@ -148,6 +199,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                 sxh[dst] = sxh[src];
                 sxl[dst] = sxl[src];
             }
+            if (tid == 0) sinv[0] = sinv[BE_TT];
             __syncthreads();                          // row 15 is rewritten by this tile's last frame
         }
         BE_STAMP(17);
@@ -193,31 +245,39 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                 // copy into the transpose buffer, then rows of four channels like any other frame
                 for (int i = tid; i < 2 * C * NF; i += BE_NT) tbuf[i] = dbuf_in[(long)b * 2 * C * NF + i];
                 __syncthreads();
+                float tm[2] = {0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < BE_NLD; ++i) {
-                    const int e = tv + BE_NT * i;
-                    if (e < NF * 16) {
-                        const int f = e >> 4, c0 = (e & 15) * 4;
+                    const int e = min(tv + BE_NT * i, NF * 16 - 1);
+                    const int f = e >> 4, c0 = (e & 15) * 4;
 #pragma unroll
-                        for (int q = 0; q < 2; ++q)
-                            store_split4<FR_RP>(ahi + q * FR_A, alo + q * FR_A, f, c0,
-                                                make_float4(tbuf[((c0 + 0) * 2 + q) * NF + f], tbuf[((c0 + 1) * 2 + q) * NF + f],
-                                                            tbuf[((c0 + 2) * 2 + q) * NF + f], tbuf[((c0 + 3) * 2 + q) * NF + f]));
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 hv = make_float4(tbuf[((c0 + 0) * 2 + q) * NF + f], tbuf[((c0 + 1) * 2 + q) * NF + f],
+                                                      tbuf[((c0 + 2) * 2 + q) * NF + f], tbuf[((c0 + 3) * 2 + q) * NF + f]);
+                        tm[q] = stage_row(ahi + q * FR_A, alo + q * FR_A, rinv[q], tv + BE_NT * i, hv, tm[q]);
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const float wm = wave_max(tm[q]); if (lane == 0) wmax[q][wave] = wm; }
                 __syncthreads();
                 zero_guards();                        // the buffer ran over guard rows; the products below write rows 1..97 only
             } else {
+                float tm[2] = {0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < BE_NLD; ++i) {
-                    const int e = tv + BE_NT * i;
-                    if (e < NF * 16) {
-                        store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[u][i]);
-                        if (two) store_split4<FR_RP>(ahi + FR_A, alo + FR_A, e >> 4, (e & 15) * 4, stg[u + 1][i]);
-                    }
+                    tm[0] = stage_row(ahi, alo, rinv[0], tv + BE_NT * i, stg[u][i], tm[0]);
+                    if (two) tm[1] = stage_row(ahi + FR_A, alo + FR_A, rinv[1], tv + BE_NT * i, stg[u + 1][i], tm[1]);
                 }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const float wm = wave_max(tm[q]); if (lane == 0) wmax[q][wave] = wm; }
             }
             __syncthreads();
+            if (tid < 2 && (tid == 0 || two)) {        // M[fr + tid] for the spectrum bounds of frames fr + tid .. + 2
+                float m = wmax[tid][0];
+#pragma unroll
+                for (int w = 1; w < BE_NT / 64; ++w) m = fmaxf(m, wmax[tid][w]);
+                fmaxr[(fr + tid + 4) & 3] = m;
+            }
             if (tr_it) BE_STAMP(12);
             // Refill the two ring slots UNCONDITIONALLY (frame index clamped to the tile: past its end the tile's last frame
             // is loaded again — a cache hit — and never used): with the loads under `if (fr + BE_RING < fr_end)` the compiler cannot count the outstanding
@@ -265,10 +325,12 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                     for (int q = 0; q < 2; ++q) {
                         if (q == 1 && !two) break;
                         const int slot = (fr + q + 4) & 3;    // fr >= -2
+                        const float4 iv4 = *reinterpret_cast<const float4*>(&rinv[q][mt * 16 + g4 * 4]);
+                        const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int f = mt * 16 + g4 * 4 + r;
-                            if (f < NF && col < BE_NP) pring[slot][f + 1][col] = am[q][r] + ac[q][r];
+                            if (f < NF && col < BE_NP) pring[slot][f + 1][col] = (am[q][r] + ac[q][r]) * iv[r];
                         }
                     }
                 }
@@ -296,10 +358,15 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                     }
                 }
                 const float vo[4] = {v.x, v.y, v.z, v.w};
+                // frames td - 1, td - 2 below -2 do not exist; their ring slots then hold maxima of frames that do (>= 0: a
+                // larger bound, still a bound)
+                float ssx, isx;
+                pow2_scale<14>(fmaf(W1, fmaxr[(td + 4) & 3] + fmaxr[(td + 3) & 3] + fmaxr[(td + 2) & 3], bmax), ssx, isx);
+                if (f == 0) sinv[jd] = isx;
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const int s = o >> 1, k = (o & 1) * NF + f;
-                    put_sx(jd, s, k, vo[o]);
+                    put_sx(jd, s, k, vo[o] * ssx);
                     if (td == T - 1) ibuf_out[((long)b * NSRC + s) * NK + k] = vo[o];      // new carried spectrum (exact fp32)
                 }
             }
@@ -343,8 +410,10 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
 #pragma unroll
                 for (int s = 0; s < NSRC; ++s) {
                     const f32x4 acc = mma_tile<BE_NJ, BE_SK>(sxh + s * BE_SA, sxl + s * BE_SA, 0, g4, l15, wfh, wfl, 0.f);
+                    const float4 iv4 = *reinterpret_cast<const float4*>(&sinv[g4 * 4]);      // 1 / scale of spectra g4*4 ..
+                    const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) frs[g4 * 4 + r][s][(2 * wave + i) * 16 + l15] = acc[r];
+                    for (int r = 0; r < 4; ++r) frs[g4 * 4 + r][s][(2 * wave + i) * 16 + l15] = acc[r] * iv[r];
                 }
             }
         }
@@ -357,10 +426,13 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             const int n = i % HOP, s = (i / HOP) % NSRC, jt = i / (HOP * NSRC);
             float v = frs[jt + 1][s][n];
             if (n < NFFT - HOP) v += frs[jt][s][n + HOP];
-            wave_out[((long)b * NSRC + s) * L + (long)(t0 + jt) * HOP + n] = v;
-            bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;      // inf / NaN: the fp16 split overflowed upstream
+            // inf / NaN: the fp16 split overflowed upstream (or the input held inf / NaN).  The sample is stored as 0 —
+            // silence, not NaN, reaches a listener — and the CALLER's flag word is raised (range contract, lookonce_hip.h)
+            const bool nf = (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;
+            wave_out[((long)b * NSRC + s) * L + (long)(t0 + jt) * HOP + n] = nf ? 0.f : v;
+            bad |= nf;
         }
-        if (bad) atomicOr(&lh_range_flag, 1u);        // sticky, read by lh_range_status (include/lookonce_hip.h)
+        if (bad && range_flag) atomicOr(range_flag, 1u);      // sticky until lh_range_status / lh_range_flag_copy fetch it
         __syncthreads();
         // frs lived in the hi A images: their pad rows (97..111 feed dropped outputs) must hold finite numbers again —
         // only those: the 97 real rows are rewritten by the staging of the next frames
@@ -391,8 +463,8 @@ extern "C" int lh_probe_be_trace_read(unsigned long long* host_dst) {
 
 extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out,
                                const float* istft_buf_in, float* istft_buf_out, const void* wdec_pk,
-                               const float* bdec, const void* wfb_dec, float* wave_out, int B, int T,
-                               lh_stream_t stream) {
+                               const float* bdec, const void* wfb_dec, float* wave_out, unsigned* range_flag, int B,
+                               int T, lh_stream_t stream) {
     using namespace lh;
     if (!y || !deconv_buf_in || !deconv_buf_out || !istft_buf_in || !istft_buf_out || !wdec_pk || !bdec || !wfb_dec ||
         !wave_out || B <= 0 || T <= 0)
@@ -405,43 +477,40 @@ extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float
     const int n_runs = B * runs_per_b;
     hipLaunchKernelGGL(k_deconv_istft, dim3(n_runs < 256 ? n_runs : 256), dim3(BE_NT), 0, (hipStream_t)stream, y,
                        deconv_buf_in, deconv_buf_out, istft_buf_in, istft_buf_out, (const _Float16*)wdec_pk, bdec,
-                       (const _Float16*)wfb_dec, wave_out, B, T, runs_per_b);
+                       (const _Float16*)wfb_dec, wave_out, range_flag, B, T, runs_per_b);
     return check_launch();
 }
 
-// ---- range contract of the split-precision arithmetic (include/lookonce_hip.h)
-static unsigned* range_flag_addr() {          // device address of the flag on the CURRENT device (symbol lookup once per device)
-    static unsigned* addr[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!addr[dev]) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lh::lh_range_flag)) != hipSuccess) return nullptr;
-        addr[dev] = static_cast<unsigned*>(p);
-    }
-    return addr[dev];
+// ---- range contract of the split-precision arithmetic (include/lookonce_hip.h).  The flag is CALLER-OWNED device memory:
+// two 32-bit words, [0] = the sticky word lh_deconv_istft raises, [1] = the value the last fetch took out of it.  One
+// atomicExch moves [0] to [1] and clears it, so a flag raised between "read" and "clear" cannot be lost, and a caller
+// can only ever consume its own forwards' flag (round 3 kept ONE word per device that every Net / Streamer shared).
+namespace lh {
+__global__ void k_range_fetch(unsigned* flag) { flag[1] = atomicExch(&flag[0], 0u); }
+}  // namespace lh
+static int range_fetch(unsigned* flag, lh_stream_t stream) {
+    if (!flag) return LH_ERR_ARG;
+    hipLaunchKernelGGL(lh::k_range_fetch, dim3(1), dim3(1), 0, (hipStream_t)stream, flag);
+    return lh::check_launch();
 }
-extern "C" int lh_range_flag_copy(void* host_pinned, lh_stream_t stream) {
+extern "C" int lh_range_flag_copy(unsigned* flag, void* host_pinned, lh_stream_t stream) {
     if (!host_pinned) return LH_ERR_ARG;
-    unsigned* p = range_flag_addr();
-    if (!p) return LH_ERR_LAUNCH;
-    return hipMemcpyAsync(host_pinned, p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess
+    const int rc = range_fetch(flag, stream);
+    if (rc != LH_OK) return rc;
+    return hipMemcpyAsync(host_pinned, flag + 1, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess
                ? LH_OK : LH_ERR_LAUNCH;
 }
-extern "C" int lh_range_flag_clear(lh_stream_t stream) {
-    unsigned* p = range_flag_addr();
-    if (!p) return LH_ERR_LAUNCH;
-    return hipMemsetAsync(p, 0, sizeof(unsigned), (hipStream_t)stream) == hipSuccess ? LH_OK : LH_ERR_LAUNCH;
+extern "C" int lh_range_flag_clear(unsigned* flag, lh_stream_t stream) {
+    if (!flag) return LH_ERR_ARG;
+    return hipMemsetAsync(flag, 0, 2 * sizeof(unsigned), (hipStream_t)stream) == hipSuccess ? LH_OK : LH_ERR_LAUNCH;
 }
-extern "C" int lh_range_status(lh_stream_t stream) {
+extern "C" int lh_range_status(unsigned* flag, lh_stream_t stream) {
     unsigned v = 0;
-    unsigned* p = range_flag_addr();
-    if (!p || hipMemcpyAsync(&v, p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
-        return LH_ERR_LAUNCH;
+    const int rc = range_fetch(flag, stream);
+    if (rc != LH_OK) return rc;
+    if (hipMemcpyAsync(&v, flag + 1, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return LH_ERR_LAUNCH;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return LH_ERR_LAUNCH;
-    if (!v) return LH_OK;
-    if (lh_range_flag_clear(stream) != LH_OK) return LH_ERR_LAUNCH;
-    return LH_ERR_RANGE;
+    return v ? LH_ERR_RANGE : LH_OK;
 }
 
 namespace lh {

@@ -111,6 +111,36 @@ __device__ __forceinline__ float group16_sum(float v) {
     return row_ror_add<1>(v);
 }
 
+// max over aligned groups of 16 lanes (every lane of the group gets it)
+__device__ __forceinline__ float group16_max(float v) {
+    v = fmaxf(v, row_ror_mov<8>(v));
+    v = fmaxf(v, row_ror_mov<4>(v));
+    v = fmaxf(v, row_ror_mov<2>(v));
+    return fmaxf(v, row_ror_mov<1>(v));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = group16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+
+// Range-safe split (range contract, include/lookonce_hip.h).  The fp16 hi half of a split overflows at
+// 65504 and loses bits below 2^-14, so a kernel that splits UN-NORMALISED data (waveform, residual stream, spectra)
+// first multiplies the row / tile by an exact power of two  s = 2^(TE - floor(log2 m))  that brings its maximum
+// magnitude m into [2^TE, 2^(TE+1)), and multiplies the fp32 accumulator by 1/s afterwards (both exact; everything
+// between is linear or positively homogeneous).  Precision then is ~22 bits relative to the row maximum for ANY finite
+// m — the reference's plain-fp32 behaviour — instead of relative to 1.0 with a hard overflow at 65504.
+// m = 0 / subnormal and m = inf / NaN clamp to the ends (a non-finite row stays non-finite and is flagged downstream).
+template <int TE>
+__device__ __forceinline__ void pow2_scale(float maxabs, float& s, float& inv_s) {
+    static_assert(TE >= 1 && TE <= 14, "scaled maximum must stay below the fp16 range");
+    int e = (int)((__float_as_uint(maxabs) >> 23) & 0xffu);            // biased exponent of the maximum
+    e = min(max(e, TE + 1), 254);
+    s = __uint_as_float((unsigned)(254 + TE - e) << 23);               // 2^(TE - (e - 127))
+    inv_s = __uint_as_float((unsigned)(e - TE) << 23);                 // 2^((e - 127) - TE)
+}
+__device__ __forceinline__ float absmax4(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
 __device__ __forceinline__ float wave_sum(float v) {
     v = group16_sum(v);
     v += __shfl_xor(v, 16);

@@ -38,6 +38,12 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
     __shared__ __attribute__((aligned(16))) _Float16 sth[(NF + 2) * FE_SP];
     __shared__ __attribute__((aligned(16))) _Float16 stl[(NF + 2) * FE_SP];
     __shared__ __attribute__((aligned(16))) float outs[2][NF * FE_OP];
+    // Range-safe splits (pow2_scale, lh_common.h): ONE power of two per tile, from the largest sample magnitude of its 16
+    // frames (and 1/32 of the largest carried spectrum value: a filter row's L1 norm is < 23, so a spectrum value is below
+    // 32 x the sample maximum), brings the samples into [2^9, 2^10) and the spectra below 2^15; both contractions are
+    // linear, so the scale is undone once, on the conv accumulator (the bias joins after it).  A quiet recording (x 1e-4)
+    // keeps its 22 bits, a hot one (x 1e3) does not overflow the fp16 halves.
+    __shared__ float tmax[FE_NTH / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
     // resident B fragments: filterbank tiles wave, wave + 8; conv weights of channel tile wave & 3
@@ -60,7 +66,8 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
         const int b = tile / tiles_per_b;
         const int t0 = (tile % tiles_per_b) * FE_TT;
         const int nt_out = min(FE_TT, T - t0);
-        __syncthreads();                       // previous tile fully consumed (A images / specT / outs)
+        __syncthreads();                       // previous tile fully consumed (A images / specT / outs / tmax)
+        float tsc, tinv;                       // this tile's scale and its inverse
 
         // stage the 16 frames of both microphones: frame j = samples (t0-2+j)*128 .. +192, 48 float4 each
         {
@@ -75,11 +82,22 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
                 if (t >= 0 && t < T)
                     stg[i] = *reinterpret_cast<const float4*>(&x[((long)b * NMIC + m) * n_samples + (long)t * HOP + c4 * 4]);
             }
+            float tm = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) tm = fmaxf(tm, absmax4(stg[i]));
+            if (t0 == 0)                               // carried halo frames enter the same spectrum tile (workgroup-uniform)
+                for (int i = tid; i < 4 * 2 * NF; i += FE_NTH) tm = fmaxf(tm, fabsf(cbuf_in[(long)b * 4 * 2 * NF + i]) * (1.0f / 32.0f));
+            tm = wave_max(tm);
+            if (lane == 0) tmax[wave] = tm;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < FE_NTH / 64; ++w) tm = fmaxf(tm, tmax[w]);
+            pow2_scale<9>(tm, tsc, tinv);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int e = tid + FE_NTH * i;
                 const int m = e / (FE_NJ * 48), j = (e / 48) % FE_NJ, c4 = e % 48;
-                const float v[4] = {stg[i].x, stg[i].y, stg[i].z, stg[i].w};
+                const float v[4] = {stg[i].x * tsc, stg[i].y * tsc, stg[i].z * tsc, stg[i].w * tsc};
                 f16x4 h4, l4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -125,15 +143,15 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int j = g4 * 4 + r, t = t0 - 2 + j;
-                        float v = am[i][r] + ac[i][r];
-                        if (t < 0) v = cbuf_in[(((long)b * 4 + ch) * 2 + (t + 2)) * NF + f];   // carried halo frames
+                        float v = am[i][r] + ac[i][r];             // spectrum value times the tile scale
+                        if (t < 0) v = cbuf_in[(((long)b * 4 + ch) * 2 + (t + 2)) * NF + f] * tsc;   // carried halo frames
                         if (t >= T) v = 0.0f;
                         _Float16 h, l;
                         split_hl(v, h, l);
                         sth[(f + 1) * FE_SP + j * 4 + ch] = h;
                         stl[(f + 1) * FE_SP + j * 4 + ch] = l;
-                        // new halo state = the last two frames of the halo-extended spectrum (exact fp32)
-                        if (t >= T - 2 && t < T) cbuf_out[(((long)b * 4 + ch) * 2 + (t - (T - 2))) * NF + f] = v;
+                        // new halo state = the last two frames of the halo-extended spectrum (exact fp32, unscaled)
+                        if (t >= T - 2 && t < T) cbuf_out[(((long)b * 4 + ch) * 2 + (t - (T - 2))) * NF + f] = v * tinv;
                     }
                 }
             }
@@ -159,7 +177,7 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
                     };
                     ah[0] = rd8(sth, a0); al[0] = rd8(stl, a0);
                     ah[1] = rd8(sth, a1); al[1] = rd8(stl, a1);
-                    f32x4 am = f32x4{cbias, cbias, cbias, cbias}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], wch[ks], am, 0, 0, 0);
@@ -169,7 +187,7 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int fo = mt * 16 + g4 * 4 + r;
-                        if (fo < NF) ob[fo * FE_OP + cnt * 16 + l15] = am[r] + ac[r];
+                        if (fo < NF) ob[fo * FE_OP + cnt * 16 + l15] = fmaf(am[r] + ac[r], tinv, cbias);
                     }
                 }
             }
@@ -255,7 +273,7 @@ extern "C" int lh_embed_proj_ln(const float* emb, const float* w, const float* b
     return check_launch();
 }
 
-extern "C" int lh_abi_version(void) { return 11; }
+extern "C" int lh_abi_version(void) { return 12; }
 
 extern "C" int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unused, int lstm_hidden,
                                int n_heads, int attn_window, int n_srcs, int spk_emb_dim) {

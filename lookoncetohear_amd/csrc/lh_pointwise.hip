@@ -196,6 +196,9 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float yf[Y_N];
+    // the input is the un-normalised residual stream: every row is scaled by its own power of two before the split and
+    // the accumulator rows by the inverse (frame_store_scaled, lh_split.h) — Linear is linear, the bias joins afterwards
+    __shared__ __attribute__((aligned(16))) float rinv[FR_RP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
 
     // wave w owns output-column tiles w and w+4 (of 7): Q|K|V columns 16w.. and 64+16w..
@@ -216,6 +219,7 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     const int base1 = Y_V0 + (cv / VD) * DV + cv % VD;
 
     frame_zero_pad(ahi, alo, tid);
+    if (tid < FR_RP - NF) rinv[NF + tid] = 0.f;                // pad rows: finite
     for (int i = tid; i < 2 * NH * (YQS - DQK); i += 256)      // pad entries 582.. of the Q / K heads stay zero
         yf[(i / (YQS - DQK)) * YQS + DQK + i % (YQS - DQK)] = 0.f;
     float4 stg[FR_NLD];
@@ -228,25 +232,27 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
         const int b = fr / T, t = fr % T;
         QKV_STAMP(0);
-        frame_store(ahi, alo, tid, stg);
+        frame_store_scaled(ahi, alo, rinv, tid, stg);
         __syncthreads();                      // image complete; also orders the previous frame's reads of `yf`
         QKV_STAMP(1);
         if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
         // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check
         auto row_tile = [&](int m, auto checked) {
-            const f32x4 r0 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh0, wl0, bz0);
+            const f32x4 r0 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh0, wl0, 0.f);
+            const float4 iv4 = *reinterpret_cast<const float4*>(&rinv[m * 16 + g4 * 4]);     // 1 / scale of this lane's 4 rows
+            const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m * 16 + g4 * 4 + r;
-                if (!checked.value || row < NF) yf[base0 + row * str0] = prelu_f(r0[r], a0);
+                if (!checked.value || row < NF) yf[base0 + row * str0] = prelu_f(fmaf(r0[r], iv[r], bz0), a0);
             }
             if (two) {
-                const f32x4 r1 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh1, wl1, bz1);
+                const f32x4 r1 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh1, wl1, 0.f);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m * 16 + g4 * 4 + r;
-                    if (!checked.value || row < NF) yf[base1 + row * VD] = prelu_f(r1[r], sv);
+                    if (!checked.value || row < NF) yf[base1 + row * VD] = prelu_f(fmaf(r1[r], iv[r], bz1), sv);
                 }
             }
         };

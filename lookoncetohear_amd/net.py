@@ -154,10 +154,15 @@ class Net(nn.Module):
         # covers: the frame kernels — STFT / conv, Q/K/V, attention, projection, deconv / iSTFT — are split-precision in
         # every mode; "f32" is accepted as the old spelling).  LOOKONCE_GEMM overrides.
         self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
-        # range contract of the split-precision kernels (include/lookonce_hip.h): values they split must stay below 65504.
-        # With `range_check` every forward ends with lh_range_status (one 4-byte copy + a wait on the launch stream) and
-        # raises instead of returning inf / NaN; a `Streamer` polls the same flag one chunk late.
+        # range guard of the split-precision kernels (include/lookonce_hip.h): the frame kernels scale every row / tile by
+        # a power of two before they split it, so any finite input is in range; non-finite output samples (inf / NaN in
+        # the input, a true fp32 overflow) are stored as 0 and raise THIS Net's flag word (`_range_flag`, one per device,
+        # never shared with another Net or a Streamer).  With `range_check` every forward ends with lh_range_status (an
+        # exchange kernel + 4-byte copy + a wait on the launch stream) and raises; a `Streamer` polls its own flag.
+        # The check is skipped while the stream is being captured into a HIP graph (a wait is illegal there): poll
+        # `net.range_status(stream)` after the replay instead.
         self.range_check = os.environ.get("LOOKONCE_RANGE_CHECK", "1") != "0"
+        self._range_flags: Dict[str, torch.Tensor] = {}
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
         self.fuse_intra_min_frames = 8192
@@ -293,6 +298,27 @@ class Net(nn.Module):
                       gain_raw=e(B, F_ * C_), hist_dirty=False)
             self._ws[key] = ws
         return ws
+
+    def _range_flag(self, device) -> torch.Tensor:
+        """This Net's two-word range flag on `device` (include/lookonce_hip.h: [0] sticky, [1] last fetched value)."""
+        key = str(device)
+        if key not in self._range_flags:
+            self._range_flags[key] = torch.zeros(2, dtype=torch.int32, device=device)
+        return self._range_flags[key]
+
+    def range_status(self, device=None) -> bool:
+        """Fetch-and-clear this Net's range flag on the current stream of `device` (waits for the stream).  True when a
+        forward since the last check stored a zero in place of a non-finite sample.  For callers that run with
+        `range_check = False` or replay the forward from a HIP graph."""
+        dev = torch.device(device) if device is not None else next(iter(self._range_flags.values())).device
+        flag = self._range_flag(dev)
+        lib = self._lib(flag)
+        with _device_of(flag):
+            st = torch.cuda.current_stream(dev).cuda_stream if flag.is_cuda else 0
+            rc = lib.raw("lh_range_status")(flag.data_ptr(), st)
+        if rc not in (0, 4):
+            raise RuntimeError(f"lh_range_status failed: {_cabi.ERRORS.get(rc, rc)}")
+        return rc == 4
 
     def _zero_state(self, B, device) -> dict:
         key = (B, str(device))
@@ -433,23 +459,23 @@ class Net(nn.Module):
             dec_in, ist_in = c32(state["deconv_buf"]), c32(state["istft_buf"])
             dec_out, ist_out = new(dec_in), new(ist_in)
             y = torch.empty(Bn, self.n_srcs, hop * T, device=dev, dtype=torch.float32)
+            flag = self._range_flag(dev)
             lib.call("lh_deconv_istft", P(xa), P(dec_in), P(dec_out), P(ist_in), P(ist_out), P(pk["deconv_w"]),
-                     P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), Bn, T, st)
+                     P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), P(flag), Bn, T, st)
             if want_state:
                 state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
-            if self.range_check:
-                self._raise_on_range(lib_, st)
+            if self.range_check and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self._raise_on_range(lib_, flag, st)
         return y, (state if want_state else None)
 
     @staticmethod
-    def _raise_on_range(lib, stream):
-        rc = lib.raw("lh_range_status")(stream)
+    def _raise_on_range(lib, flag, stream):
+        rc = lib.raw("lh_range_status")(flag.data_ptr(), stream)
         if rc == 4:
             raise RuntimeError(
-                "LH_ERR_RANGE: the forward produced non-finite samples. The split-precision (fp16 hi + lo) kernels need "
-                "every value they split below 65504; the un-normalised residual stream of this network / input exceeded it "
-                "(or the input held inf / NaN). No arithmetic mode of this library covers that range: gemm_mode='f32rec' "
-                "only makes the two recurrences exact fp32 (include/lookonce_hip.h, range contract).")
+                "LH_ERR_RANGE: the forward produced non-finite samples (stored as 0). The frame kernels scale every row by a "
+                "power of two before the fp16 hi + lo split, so this means inf / NaN in the input or the state, or an "
+                "activation beyond the fp32 range itself (include/lookonce_hip.h, range contract).")
         if rc != 0:
             raise RuntimeError(f"lh_range_status failed: {_cabi.ERRORS.get(rc, rc)}")
 
@@ -466,7 +492,7 @@ class Net(nn.Module):
             lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]), P(pk["emb_ln_b"]),
                      P(gain_raw), P(gain), embed.shape[0], st)
 
-    def _stream_chunk(self, x, gain, sin: dict, sout: dict, rings, pos, y, pk: dict, ws: dict):
+    def _stream_chunk(self, x, gain, sin: dict, sout: dict, rings, pos, y, pk: dict, ws: dict, flag=None):
         """One chunk of ONE frame for `Streamer`: the launches of `_separate` with every state tensor read from `sin` and
         written to `sout` (preallocated), the K / V history in per-block persistent rings, the speaker gain given.
         `pk` / `ws`: the packed weights and the T=1 workspace, OWNED by the caller — a captured graph holds raw pointers
@@ -500,7 +526,8 @@ class Net(nn.Module):
             lib.call("lh_proj_ln_res", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
                      P(bp["proj_ln_w"]), P(bp["proj_ln_b"]), P(xc), P(g) if g is not None else None, P(xa), Bn, T, st)
         lib.call("lh_deconv_istft", P(xa), P(sin["deconv_buf"]), P(sout["deconv_buf"]), P(sin["istft_buf"]),
-                 P(sout["istft_buf"]), P(pk["deconv_w"]), P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), Bn, T, st)
+                 P(sout["istft_buf"]), P(pk["deconv_w"]), P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y),
+                 P(flag) if flag is not None else None, Bn, T, st)
 
 
 
@@ -543,10 +570,12 @@ class Streamer:
         self.pos = z(1, dtype=torch.int32)
         self.gain = z(B, F_, C_)
         self.gain_raw = z(B, F_ * C_)
-        # range flag of the split-precision kernels: every RANGE_POLL-th chunk an asynchronous 4-byte copy into pinned host
-        # memory follows the chunk's launches (outside the captured graph: a copy node per chunk cost 26 us of a 0.30 ms
-        # chunk, the separate copy ~0.15 ms of the one chunk it follows), and the word is looked at when later chunks
-        # arrive — so an overflow raises within RANGE_POLL + 1 chunks
+        # range guard: THIS streamer's own two-word device flag (never shared with the Net's offline forwards or another
+        # streamer).  Every RANGE_POLL-th chunk an exchange kernel + asynchronous 4-byte copy into pinned host memory
+        # follows the chunk's launches (outside the captured graph: a copy node per chunk cost 26 us of a 0.30 ms chunk),
+        # and the word is looked at when later chunks arrive — so a non-finite chunk (output: zeros) raises within
+        # RANGE_POLL + 1 chunks
+        self.range_flag = z(2, dtype=torch.int32)
         self.range_word = torch.zeros(1, dtype=torch.int32)
         if dev.type == "cuda":
             self.range_word = self.range_word.pin_memory()
@@ -579,7 +608,7 @@ class Streamer:
             self.graph = self.graphs[0]
             self.reset()
 
-    RANGE_POLL = 64          # chunks between polls of the range flag (0.5 s of audio; a polled chunk costs ~0.15 ms more)
+    RANGE_POLL = 8           # chunks between polls of the range flag (64 ms of audio)
 
     def _version_stamp(self) -> int:
         if self.net._blob is not None:
@@ -589,7 +618,7 @@ class Streamer:
     def _body(self, k: int):
         with _device_of(self.chunk):
             self.net._stream_chunk(self.chunk, self.gain, self.sets[k], self.sets[k ^ 1], self.rings, self.pos, self.out,
-                                   self._pk, self._ws)
+                                   self._pk, self._ws, self.range_flag)
             # ring slot counter, kept in [0, window): an ever-growing int32 would go negative after 2^31 chunks and C's
             # `%` would then index before the ring.  One 1-thread kernel (two torch elementwise launches cost 9 us of the chunk)
             st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
@@ -603,6 +632,8 @@ class Streamer:
             kx.zero_()
             vx.zero_()
         self.pos.zero_()
+        self.range_flag.zero_()
+        self.range_word.zero_()
         self.parity = 0
 
     def set_embedding(self, embed: torch.Tensor):
@@ -621,11 +652,9 @@ class Streamer:
             raise RuntimeError("the Net's parameters changed after this Streamer was built (its HIP graphs hold pointers "
                                "into the old packed weights): create a new streamer with net.make_streamer(...)")
         if int(self.range_word[0]) != 0:
-            self.range_word.zero_()
-            st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-            net._lib(self.chunk).call("lh_range_flag_clear", st)
-            raise RuntimeError("LH_ERR_RANGE: an earlier chunk produced non-finite samples (fp16 split overflow of the "
-                               "residual stream, or inf / NaN in the input); reset() the streamer")
+            self.range_word.zero_()              # (the device word was cleared by the exchange that fetched it)
+            raise RuntimeError("LH_ERR_RANGE: an earlier chunk produced non-finite samples, emitted as zeros (inf / NaN in "
+                               "the input or in the carried state); reset() the streamer")
         # ... and a parameter updated IN PLACE (optimizer step, load_state_dict) without any other `Net` call in between
         # would replay silently on the old images: a cheap version stamp (sum of the tensors' version counters) every
         # 64th chunk catches it within half a second of audio
@@ -642,6 +671,6 @@ class Streamer:
             if net.range_check and (self._n_steps % self.RANGE_POLL) == 0:
                 st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
                 with _device_of(self.chunk):
-                    net._lib(self.chunk).call("lh_range_flag_copy", self.range_word.data_ptr(), st)
+                    net._lib(self.chunk).call("lh_range_flag_copy", self.range_flag.data_ptr(), self.range_word.data_ptr(), st)
         self.parity ^= 1
         return self.out

@@ -291,22 +291,54 @@ def test_streamer_ring_and_pingpong(emu_net, oracle_cfg_sd):
     assert torch.equal(torch.cat(outs2, -1), torch.cat(outs[:3], -1))
 
 
-def test_range_contract_raises_instead_of_returning_nan(emu_net):
-    """Range contract of the split-precision kernels (include/lookonce_hip.h): an input beyond the fp16 range of the hi
-    halves (|v| >= 65504) turns the frame's products into NaN; the back end flags the non-finite samples and
-    `Net.forward` raises LH_ERR_RANGE instead of returning them.  The flag is cleared by the read: the next forward is
-    clean.  The `Streamer` polls the same flag one chunk late."""
+def test_any_finite_input_scale_matches_the_oracle(emu_net, oracle_cfg_sd):
+    """Range-safe splits (pow2_scale, lh_common.h): the kernels that split un-normalised data scale
+    each row / tile by a power of two first, so a mixture 1e-4 x or 1e6 x the nominal level — far outside what an
+    unscaled fp16 hi half can hold — is separated like the plain-fp32 reference does it (tfgridnet_causal.py:188-283):
+    finite, and within the tolerance relative to the output amplitude against the fp64 oracle."""
+    cfg, sd = oracle_cfg_sd
+    d = synth.batch([1], 128 * 5 + 64)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    for scale in (1e-4, 1e-2, 1.0, 1e2, 1e6):
+        mix = d["mixture"] * scale
+        y = emu_net(mix, d["embedding_gt"])
+        yo = O.forward(cfg, sd64, mix.double(), d["embedding_gt"].double())
+        amp = float(yo.abs().max())
+        assert torch.isfinite(y).all()
+        assert float((y.double() - yo).abs().max()) < TOL * max(amp, 1.0), (scale, amp)
+
+
+def test_range_guard_is_per_caller_and_emits_silence(emu_net, oracle_cfg_sd):
+    """Range guard (include/lookonce_hip.h): a NaN / inf that reaches the back end is stored as 0 and raises the CALLER's
+    flag word — `Net.forward` raises LH_ERR_RANGE, the exchange clears the flag (next forward clean), and a second Net or a
+    Streamer on the same device keeps its own word: it neither sees nor clears the first one's flag."""
+    cfg, sd = oracle_cfg_sd
     d = synth.batch([1], 128 * 3)
-    big = d["mixture"] * 1e6
+    bad = d["mixture"].clone()
+    bad[0, 0, 100] = float("nan")
+    other = Net(**O.TSH_PARAMS).eval()
+    other.load_state_dict(sd, strict=True)
+    other._lib_override = emu_net._lib_override
+    emu_net.range_check = False
+    try:
+        y = emu_net(bad, d["embedding_gt"])                # flag raised, not consumed
+    finally:
+        emu_net.range_check = True
+    assert torch.isfinite(y).all() and (y == 0).any()      # silence instead of NaN
+    yo = other(d["mixture"], d["embedding_gt"])            # the other Net's check must not see (or clear) it
+    assert torch.isfinite(yo).all()
+    assert emu_net.range_status("cpu") is True             # still pending for its owner ...
+    assert emu_net.range_status("cpu") is False            # ... and cleared by the fetch
     with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
-        emu_net(big, d["embedding_gt"])
-    y = emu_net(d["mixture"], d["embedding_gt"])
-    assert torch.isfinite(y).all()
+        emu_net(bad, d["embedding_gt"])
+    assert torch.equal(emu_net(d["mixture"], d["embedding_gt"]), yo)
     st = emu_net.make_streamer(1, "cpu", use_graph=False)
-    st.RANGE_POLL = 2                                     # (16 on the product path: 128 ms of audio)
+    st.RANGE_POLL = 2
     st.set_embedding(d["embedding_gt"][:, 0])
     st.step(d["mixture"][:, :, :192])
-    st.step(big[:, :, :192])                              # produces NaN; polled after this chunk, noticed at the next one
+    out = st.step(bad[:, :, :192]).clone()                 # non-finite chunk; polled after it, noticed at the next one
+    assert torch.isfinite(out).all()
+    assert emu_net.range_status("cpu") is False            # the streamer's flag is not the Net's
     with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
         st.step(d["mixture"][:, :, :192])
     st.reset()
