@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
     // gate bias as a factor: the packed bias carries the gate's exponent scale, 1 + 2^(a + b) = fma(2^a, 2^b, 1)
     float eb[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) eb[g] = __builtin_amdgcn_exp2f(b_sum[dir * 256 + g * 64 + unit]);
+    for (int g = 0; g < 4; ++g)      // exponent clamped to +-100: 2^a may saturate to inf / 0 on its own, and inf * 0 would be NaN
+        eb[g] = __builtin_amdgcn_exp2f(fminf(fmaxf(b_sum[dir * 256 + g * 64 + unit], -100.0f), 100.0f));
     const float lbias = accumulate ? 0.0f : blin[unit];
 
     const int a_row = (tid >> 4) * XP_AP + q * 4;      // row-wise role: row tid >> 4, float4 q
@@ -499,7 +500,8 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) eb[m][g] = __builtin_amdgcn_exp2f(b_sum[dir * 256 + g * 64 + unit0 + 4 * m]);
+        for (int g = 0; g < 4; ++g)      // exponent clamped like k_intra_xp's (no inf * 0)
+            eb[m][g] = __builtin_amdgcn_exp2f(fminf(fmaxf(b_sum[dir * 256 + g * 64 + unit0 + 4 * m], -100.0f), 100.0f));
 
     const int a_frag = l15 * XP_AP + g4 * 8;
     const int a_cell = l15 * XP_AP + C + unit0;

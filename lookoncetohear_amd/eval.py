@@ -37,7 +37,10 @@ def evaluate(model: Callable, data_fn: Callable[[List[int]], dict], n_utts: int,
             target = d["target"].to(device)
             emb_gt = d["embedding_gt"].to(device)
             if enroll_model is not None:                     # ts_hear_test.py:132-135
-                embedding = enroll_model(d["enrollments"].to(device)).unsqueeze(1)
+                enrollments = d["enrollments"]
+                if enrollments.dim() == 4:                   # [B, num_enroll = 1, 2, N] as the dataset returns it
+                    enrollments = enrollments.squeeze(1)
+                embedding = enroll_model(enrollments.to(device)).unsqueeze(1)
             else:
                 embedding = emb_gt                           # :137
             outputs = model(mixture, embedding)              # :138  <- the hot path

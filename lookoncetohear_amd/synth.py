@@ -71,8 +71,23 @@ def utterance(idx: int, n: int = 80000):
     return mix.astype(np.float32), tgt.astype(np.float32), emb[None].astype(np.float32)
 
 
-def batch(indices, n: int = 80000):
-    """Stack utterances -> dict of torch CPU tensors: mixture [B,2,n], target [B,2,n], embedding_gt [B,1,256]."""
+ENROLL_SEED_OFFSET = 1_000_003          # the enrollment recording of utterance i is synthetic utterance i + this
+
+
+def enrollment(idx: int, n: int = 80000) -> np.ndarray:
+    """[1, 2, n] float32: the noisy binaural enrollment recording the reference dataset returns as `inputs['enrollments']`
+    (`num_enroll` = 1 recordings of `enroll_len` = 5 s: MixLibriSpeechNoisyEnrollNorm.py:118, 259-303 — another scene
+    with the target speaker in it, rendered like a mixture).  Synthetic stand-in: the mixture of an unrelated synthetic
+    utterance, seeded by the utterance index like everything else here."""
+    return utterance(ENROLL_SEED_OFFSET + int(idx), n)[0][None]
+
+
+def batch(indices, n: int = 80000, enroll_n: int = 0):
+    """Stack utterances -> dict of torch CPU tensors: mixture [B,2,n], target [B,2,n], embedding_gt [B,1,256] and, with
+    `enroll_n` > 0, enrollments [B,1,2,enroll_n] (the eval loop squeezes dim 1, reference src/ts_hear_test.py:133)."""
     m, t, e = zip(*(utterance(int(i), n) for i in indices))
-    return dict(mixture=torch.from_numpy(np.stack(m)), target=torch.from_numpy(np.stack(t)),
-                embedding_gt=torch.from_numpy(np.stack(e)))
+    out = dict(mixture=torch.from_numpy(np.stack(m)), target=torch.from_numpy(np.stack(t)),
+               embedding_gt=torch.from_numpy(np.stack(e)))
+    if enroll_n:
+        out["enrollments"] = torch.from_numpy(np.stack([enrollment(int(i), enroll_n) for i in indices]))
+    return out

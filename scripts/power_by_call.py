@@ -97,8 +97,9 @@ seen, tot_ms, tot_j = {}, 0.0, 0.0
 count = {}
 for name, _ in rec.calls:
     count[name] = count.get(name, 0) + 1
+ONLY = set(filter(None, os.environ.get("PROBE_CALLS", "").split(",")))      # e.g. lh_intra_block,lh_inter_block
 for name, args in rec.calls:
-    if name in seen:
+    if name in seen or (ONLY and name not in ONLY):
         continue
     seen[name] = True
     a, b = measure(lambda: lib.call(name, *args), name, count[name])

@@ -468,3 +468,42 @@ def test_ring_advance_wraps(emu_net):
         assert pos.item() == want
     assert lib.raw("lh_ring_advance")(ctypes.c_void_p(pos.data_ptr()), 0, None) == 1          # LH_ERR_ARG
     assert lib.raw("lh_ring_advance")(None, 50, None) == 1
+
+
+def test_enroll_then_separate_chain_on_the_emulator(emu_net, oracle_cfg_sd):
+    """The eval loop's hot sequence (reference src/ts_hear_test.py:132-138) on the emulated kernels:
+    `eval.evaluate(net, ..., enroll_model=embedder)` = enrollments.squeeze(1) -> embedder -> unsqueeze(1) -> separator ->
+    metric rows, against the oracle chain.  Tiny shapes (2 utterances, 3 mixture frames, 21 enrollment frames); the GPU
+    version is tests/test_gpu_chain.py."""
+    from tests.hipemu.build_emu import build_emu
+    from lookoncetohear_amd.embed_net import EmbedTFGridNet
+    from lookoncetohear_amd.eval import evaluate
+    from lookoncetohear_amd.metrics import per_utterance
+    from oracle import embedder_oracle as E
+    cfg, sd = oracle_cfg_sd
+    ecfg = E.ECfg(**E.EMBED_PARAMS)
+    esd = E.synthetic_state_dict(ecfg, 0)
+    enet = EmbedTFGridNet(**E.EMBED_PARAMS).eval()
+    enet.load_state_dict(esd, strict=True)
+    enet._lib_override = _cabi.Lib(build_emu())
+    data_fn = lambda idx: synth.batch(idx, 128 * 3, enroll_n=1280)
+    kept = []
+
+    def model(mixture, embedding):
+        y = emu_net(mixture, embedding)
+        kept.append((y, embedding))
+        return y
+
+    res, rows = evaluate(model, data_fn, 2, batch_size=2, device="cpu", enroll_model=enet)
+    d = data_fn([0, 1])
+    assert d["enrollments"].shape == (2, 1, 2, 1280)
+    emb_o = E.forward(ecfg, esd, d["enrollments"].squeeze(1), dtype=torch.float64)
+    y_o = O.forward(cfg, {k: v.double() for k, v in sd.items()}, d["mixture"].double(), emb_o.unsqueeze(1))
+    y, emb = kept[0]
+    assert float((emb[:, 0].double() - emb_o).abs().max()) < TOL
+    assert float((y.double() - y_o).abs().max()) < TOL
+    o_sisnr, o_snri, o_cos = per_utterance(y_o.float(), d["mixture"], d["target"], emb_o.float(), d["embedding_gt"][:, 0])
+    for r in rows:
+        assert abs(r["output_sisnr"] - float(o_sisnr[r["idx"]])) < 0.05 and abs(r["si_snr_i"] - float(o_snri[r["idx"]])) < 0.05
+        assert abs(r["embedding_sim"] - float(o_cos[r["idx"]])) < 1e-5
+    assert res["n"] == 2
