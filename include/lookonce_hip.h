@@ -276,6 +276,16 @@ int lh_emb_axis(const float* x, const void* wih_pk, const float* bih, const void
                 const float* bct, void* xsplit, float* gx, float* hbuf, float* out, int B, int T, int inter,
                 lh_stream_t stream);
 
+/* The same axis path without the gate pre-activation round trip (round 4): LayerNorm + split -> ONE recurrent kernel that
+ * computes the 256-wide input half one step ahead of the dependent chain (weights resident in registers, one workgroup of
+ * 16 sequences x one direction per CU) and writes the hidden states as fp16 hi | lo images -> transposed-conv GEMM + residual.
+ *   wrec_pk  fp16 [2 dirs][8 waves][40 fragments][64 lanes][8]: MFMA A fragments of [W_ih (4 window slots) | W_hh], rows
+ *            ordered (unit, gate), LayerNorm gamma and the gates' exponent factors folded in (embed_net.py pack_rec)
+ *   brec     [2][256] in (unit, gate) order, same folding;  wct_pk, bct as lh_emb_axis
+ *   xsplit   scratch 2*B*T*65*64 fp16;  hsplit scratch 2*nseq*P*128 fp16 (hi | lo images of the hidden states) */
+int lh_emb_axis_fused(const float* x, const void* wrec_pk, const float* brec, const void* wct_pk, const float* bct,
+                      void* xsplit, void* hsplit, float* out, int B, int T, int inter, lh_stream_t stream);
+
 /* Enrollment embedder, attention branch of one GridNetBlock (espnet2 GridNetBlock.forward attention part, restated in
  * oracle/embedder_oracle.py:149-168): per-head Q/K/V 1x1 conv + PReLU + LayerNorm over (channel, bin), full T x T
  * softmax attention per (head, utterance), head merge, attn_concat_proj (1x1 conv + PReLU + LayerNorm) + residual.

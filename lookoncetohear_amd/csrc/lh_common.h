@@ -111,12 +111,21 @@ __device__ __forceinline__ float group16_sum(float v) {
     return row_ror_add<1>(v);
 }
 
-// max over aligned groups of 16 lanes (every lane of the group gets it)
+// max of NON-NEGATIVE floats over aligned groups of 16 lanes (every lane of the group gets it).  Done on the bit patterns
+// (same order as the values for v >= 0; a NaN sorts above everything, which is what the range guard wants): with the DPP
+// source defaulting to 0 — the identity of an unsigned max — hipcc folds each step into ONE v_max_u32_dpp; the float
+// version stayed v_mov_b32_dpp + v_max_f32 (0 is not fmax's identity), twice the instructions in VALU-bound frame kernels.
+template <int N>
+__device__ __forceinline__ unsigned row_ror_umax(unsigned v) {
+    const unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false);
+    return v > r ? v : r;
+}
 __device__ __forceinline__ float group16_max(float v) {
-    v = fmaxf(v, row_ror_mov<8>(v));
-    v = fmaxf(v, row_ror_mov<4>(v));
-    v = fmaxf(v, row_ror_mov<2>(v));
-    return fmaxf(v, row_ror_mov<1>(v));
+    unsigned u = __float_as_uint(v);
+    u = row_ror_umax<8>(u);
+    u = row_ror_umax<4>(u);
+    u = row_ror_umax<2>(u);
+    return __uint_as_float(row_ror_umax<1>(u));
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = group16_max(v);
@@ -139,7 +148,9 @@ __device__ __forceinline__ void pow2_scale(float maxabs, float& s, float& inv_s)
     s = __uint_as_float((unsigned)(254 + TE - e) << 23);               // 2^(TE - (e - 127))
     inv_s = __uint_as_float((unsigned)(e - TE) << 23);                 // 2^((e - 127) - TE)
 }
-__device__ __forceinline__ float absmax4(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ float absmax4(const float4& v) {        // two v_max3_f32 with |abs| source modifiers
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)), fabsf(v.w));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
     v = group16_sum(v);

@@ -553,6 +553,277 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt_res(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Round 4: the axis path without the gate pre-activation round trip.  k_emb_gx wrote Gx = [rows x 512] fp32 (10.2 GB per
+// axis pass at B = 64) and k_emb_lstm read it back: 20 of the 31 GB an axis pass moved.  k_emb_rec computes the input half
+// INSIDE the recurrent kernel, one step ahead of the dependent chain (as k_intra_xp / k_inter_xp do for the separator):
+//   * one workgroup (8 waves, one per CU: 256 registers each) = 16 sequences of ONE direction; the gate GEMM is
+//     TRANSPOSED — weights are the MFMA A operand, rows ordered (unit, gate), the 16 sequences are the N axis — so a
+//     lane's accumulator quad is (i, f, g, o) of one unit and the cell update is lane-local; wave w owns units
+//     8w .. 8w+7 as two row tiles {8w + 2u + j}, so a lane's two cells are ADJACENT units and h leaves as one 4-byte
+//     LDS store per half (hi pair, lo pair);
+//   * [W_ih (4 window slots x 64 channels) | W_hh] of the wave's 32 rows live in VGPRs as f16x3 A fragments: 128 + 32
+//     registers (the whole register file of the CU holds one direction's 327 KB of hi/lo weights — the reason for one
+//     workgroup per CU);
+//   * positions (the unfold's elements) stream through an 8-slot LDS ring of pre-split rows [hi 64 | lo 64] (k_emb_lnsplit's
+//     images, 16-byte copies, two steps of global prefetch in registers); the window of step t+1 = ring slots t+1 .. t+4;
+//   * processing order: the reverse direction runs the same code on mirrored positions (pi = L-1-p) with its window
+//     slots packed in reverse tap order (embed_net.py pack_rec), so nothing in the loop depends on the direction;
+//   * hidden states leave as fp16 hi | lo images [row][128] (forward units in columns 0..63, reverse 64..127) — the
+//     operand format of the transposed-conv GEMM that follows (k_emb_convt2), which therefore stages 16-byte copies
+//     instead of splitting every element four times.
+// Gates are pre-scaled for v_exp_f32 (weights.py gate_prescale; lstm_cell_pre).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ER_NT = 512;                 // 8 waves
+constexpr int ER_RP = 144;                 // halves per LDS row: [hi 64 | lo 64 | pad 16] — 288-byte stride, conflict-free ds_read_b128
+constexpr int ER_RING = 8;                 // position slots
+constexpr int ER_POS = 16 * ER_RP;         // halves per position slot (16 sequences)
+constexpr int ER_NFRAG = 2 * (EKS * 2 + 2) * 2;   // per wave: 2 tiles x (4 slots x 2 k-steps + 2 k-steps of W_hh) x (hi, lo) = 40
+
+template <bool INTER>
+__global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict__ xs, const _Float16* __restrict__ w_pk,
+                                                      const float* __restrict__ bias, _Float16* __restrict__ hs, int nseq,
+                                                      int P, int T, long rows_x) {
+    __shared__ __attribute__((aligned(16))) _Float16 ring[ER_RING * ER_POS];
+    __shared__ __attribute__((aligned(16))) _Float16 himg[2 * ER_POS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int dir = blockIdx.y, s0 = blockIdx.x * 16;
+    const int L = P + EKS - 1;
+    const long hrows = (long)nseq * P;
+
+    // resident A fragments
+    f16x8 wxh[2][EKS][2], wxl[2][EKS][2], whh[2][2], whl[2][2];
+    {
+        const _Float16* wp = w_pk + (((long)(dir * 8 + wave) * ER_NFRAG) * 64 + lane) * 8;
+        int f = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int k4 = 0; k4 < EKS; ++k4)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    wxh[j][k4][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(f++) * 64 * 8);
+                    wxl[j][k4][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(f++) * 64 * 8);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                whh[j][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(f++) * 64 * 8);
+                whl[j][ks] = *reinterpret_cast<const f16x8*>(wp + (long)(f++) * 64 * 8);
+            }
+        }
+    }
+    // bias of this lane's rows: tile j, unit 8w + 2 g4 + j, gates 0..3 (accumulator rows 4 g4 + gate)
+    f32x4 bz[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4 b4 = *reinterpret_cast<const float4*>(&bias[dir * 256 + (wave * 8 + 2 * g4 + j) * 4]);
+        bz[j] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+
+    // row-wise roles.  Waves 0..3 stage positions: thread -> (sequence row, 16-byte piece: 0..7 of the hi image, 8..15 lo)
+    const int rrow = (tid & 255) >> 4, piece = tid & 15;
+    const int sq = min(s0 + rrow, nseq - 1);
+    const bool loader = wave < 4;
+    const _Float16* xsrc = xs + (piece < 8 ? 0 : rows_x * C) + (piece & 7) * 8;
+    auto load_pos = [&](int pi) -> f16x8 {                    // processing-order position pi (clamped), mirrored for dir 1
+        pi = min(pi, L - 1);
+        const int p = dir ? L - 1 - pi : pi;
+        return *reinterpret_cast<const f16x8*>(&xsrc[pos_row<INTER>(sq, p, T) * C]);
+    };
+    auto put_pos = [&](int pi, const f16x8& v) {
+        *reinterpret_cast<f16x8*>(&ring[(pi & (ER_RING - 1)) * ER_POS + rrow * ER_RP + piece * 8]) = v;
+    };
+    // waves 4..7 write the hidden states of the previous step: himg row -> hi | lo images, this direction's 64 columns
+    _Float16* hdst = hs + (piece < 8 ? 0 : hrows * 128) + dir * H + (piece & 7) * 8;
+    auto flush_h = [&](int it, int buf) {                     // h of processing step it
+        if (s0 + rrow < nseq) {
+            const int t = dir ? P - 1 - it : it;
+            *reinterpret_cast<f16x8*>(&hdst[((long)(s0 + rrow) * P + t) * 128]) =
+                *reinterpret_cast<const f16x8*>(&himg[buf * ER_POS + rrow * ER_RP + piece * 8]);
+        }
+    };
+
+    // x half of the gates of processing step `it`: bias + sum over the 4 window slots (ring positions it .. it+3)
+    const int frag_off = l15 * ER_RP + g4 * 8;
+    auto gate_x = [&](int it, f32x4 (&out)[2]) {
+        f32x4 am[2] = {bz[0], bz[1]}, ac[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k4 = 0; k4 < EKS; ++k4) {
+            const _Float16* base = &ring[((it + k4) & (ER_RING - 1)) * ER_POS + frag_off];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(base + ks * 32);
+                const f16x8 xl = *reinterpret_cast<const f16x8*>(base + 64 + ks * 32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    am[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxh[j][k4][ks], xh, am[j], 0, 0, 0);
+                    ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxh[j][k4][ks], xl, ac[j], 0, 0, 0);
+                    ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxl[j][k4][ks], xh, ac[j], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) out[j] = f32x4{am[j][0] + ac[j][0], am[j][1] + ac[j][1], am[j][2] + ac[j][2], am[j][3] + ac[j][3]};
+    };
+
+    // prologue: positions 0..5 into the ring, positions 6 and 7 in flight; h_{-1} = 0
+    f16x8 stA = f16x8{0, 0, 0, 0, 0, 0, 0, 0}, stB = stA;
+    if (loader) {
+        f16x8 p0[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p0[i] = load_pos(i);
+        stA = load_pos(6);
+        stB = load_pos(7);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) put_pos(i, p0[i]);
+    } else {
+        *reinterpret_cast<f16x8*>(&himg[rrow * ER_RP + piece * 8]) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float creg[2] = {0.f, 0.f};
+    __syncthreads();
+    f32x4 gxn[2];
+    gate_x(0, gxn);
+
+    auto step = [&](int it, f16x8& stg) {
+        const int cur = it & 1;
+        // on the chain: gates = x half (computed one step ago) + W_hh h_{it-1}
+        f32x4 am[2] = {gxn[0], gxn[1]}, ac[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        {
+            const _Float16* base = &himg[cur * ER_POS + frag_off];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 hh = *reinterpret_cast<const f16x8*>(base + ks * 32);
+                const f16x8 hl = *reinterpret_cast<const f16x8*>(base + 64 + ks * 32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    am[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whh[j][ks], hh, am[j], 0, 0, 0);
+                    ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whh[j][ks], hl, ac[j], 0, 0, 0);
+                    ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whl[j][ks], hh, ac[j], 0, 0, 0);
+                }
+            }
+        }
+        // off the chain: the x half of step it + 1 (window slots = positions it+1 .. it+4, staged >= 1 barrier ago)
+        if (it + 1 < P) gate_x(it + 1, gxn);
+        // cell update: two adjacent units of sequence l15 per lane
+        float hv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            lstm_cell_pre(am[j][0] + ac[j][0], am[j][1] + ac[j][1], am[j][2] + ac[j][2], am[j][3] + ac[j][3], creg[j], hv[j]);
+        _Float16 h0, l0, h1, l1;
+        split_hl(hv[0], h0, l0);
+        split_hl(hv[1], h1, l1);
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        _Float16* hrow = &himg[(cur ^ 1) * ER_POS + l15 * ER_RP + wave * 8 + 2 * g4];
+        *reinterpret_cast<f16x2*>(hrow) = f16x2{h0, h1};
+        *reinterpret_cast<f16x2*>(hrow + 64) = f16x2{l0, l1};
+        if (loader) {                                    // position it + 6 (loaded two steps ago) -> ring; fetch it + 8
+            put_pos(it + 6, stg);
+            stg = load_pos(it + 8);
+        } else if (it > 0) {
+            flush_h(it - 1, cur);
+        }
+        __syncthreads();
+    };
+    int it = 0;
+    for (; it + 1 < P; it += 2) {
+        step(it, stA);
+        step(it + 1, stB);
+    }
+    if (it < P) step(it, stA);
+    if (!loader) flush_h(P - 1, P & 1);
+}
+
+// out[r] = x[r] + b + sum_{k<4} Wt_k h[(s, q - k)]: ConvTranspose1d(128 -> 64, 4, stride 1) + residual from k_emb_rec's
+// fp16 hi | lo hidden-state images.  One tile = 64 consecutive output positions of ONE sequence: its 67 rows of h are
+// staged once (16-byte copies, no conversion; zero rows outside 0..P-1) and the transposed conv's taps are row offsets
+// in the A-fragment address (k-step ks covers tap ks / 4, hidden columns 32 (ks & 3) ..), like k_emb_gx's unfold.
+constexpr int CT_RP = 69;                          // odd row pitch in 16-byte slots
+constexpr int CT_ROWS = 64 + EKS - 1;              // 67
+constexpr int CT_NLD = (CT_ROWS * 16 + 255) / 256; // 16-byte pieces per thread and image (5)
+template <bool INTER>
+__global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restrict__ hs, const _Float16* __restrict__ w_pk,
+                                                       const float* __restrict__ bias, const float* __restrict__ x,
+                                                       float* __restrict__ out, int nseq, int P, int T) {
+    constexpr int KS = 16, CSP = C + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[16 * CT_RP * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[16 * CT_RP * 8];
+    __shared__ __attribute__((aligned(16))) float cs[64 * CSP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    f16x8 wh[KS], wl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const _Float16* p = w_pk + ((long)(wave * KS + ks) * 64 + lane) * 16;
+        wh[ks] = *reinterpret_cast<const f16x8*>(p);
+        wl[ks] = *reinterpret_cast<const f16x8*>(p + 8);
+    }
+    const float bz = bias[wave * 16 + l15];
+    const int L = P + EKS - 1;
+    const int tps = (L + 63) / 64;
+    const int ntiles = nseq * tps;
+    const long hrows = (long)nseq * P;
+    const _Float16* hh = hs;
+    const _Float16* hl = hs + hrows * 128;
+    f16x8 sh[CT_NLD], sl[CT_NLD];
+    auto fetch = [&](int tile) {
+        const int s = tile / tps, q0 = (tile % tps) * 64;
+#pragma unroll
+        for (int i = 0; i < CT_NLD; ++i) {
+            const int e = min(tid + 256 * i, CT_ROWS * 16 - 1);
+            const int p = q0 - (EKS - 1) + (e >> 4);
+            sh[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            sl[i] = sh[i];
+            if (p >= 0 && p < P) {
+                const long off = ((long)s * P + p) * 128 + (e & 15) * 8;
+                sh[i] = *reinterpret_cast<const f16x8*>(&hh[off]);
+                sl[i] = *reinterpret_cast<const f16x8*>(&hl[off]);
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int s = tile / tps, q0 = (tile % tps) * 64;
+        const int valid = min(64, L - q0);
+#pragma unroll
+        for (int i = 0; i < CT_NLD; ++i) {
+            const int e = tid + 256 * i;
+            if (e < CT_ROWS * 16) {
+                const int idx = ((e & 15) * CT_RP + (e >> 4)) * 8;
+                *reinterpret_cast<f16x8*>(&ahi[idx]) = sh[i];
+                *reinterpret_cast<f16x8*>(&alo[idx]) = sl[i];
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+#pragma unroll 1
+        for (int m = 0; m < 4; ++m) {
+            f32x4 am = f32x4{bz, bz, bz, bz}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                // output row m*16 + l15 = position q0 + that; tap k = ks >> 2 reads h row q - k = staged row (.. + 3 - k)
+                const int idx = (((ks & 3) * 4 + g4) * CT_RP + m * 16 + l15 + (EKS - 1) - (ks >> 2)) * 8;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[(m * 16 + g4 * 4 + r) * CSP + wave * 16 + l15] = am[r] + ac[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, rr = e >> 4, c4 = e & 15;
+            if (rr < valid) {
+                const long r = pos_row<INTER>(s, q0 + rr, T);
+                const float4 cv = *reinterpret_cast<const float4*>(&cs[rr * CSP + c4 * 4]);
+                const float4 xv = *reinterpret_cast<const float4*>(&x[r * C + c4 * 4]);
+                *reinterpret_cast<float4*>(&out[r * C + c4 * 4]) = make_float4(cv.x + xv.x, cv.y + xv.y, cv.z + xv.z, cv.w + xv.w);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Attention branch of the espnet2 GridNetBlock.  Frame kernels (one [65 x 64] frame per iteration, persistent):
 //   k_emb_qkv   per head h: Conv2d 1x1 (64 -> 8 | 8 | 16) + PReLU (own slope) + LayerNorm over (c, f) with [c][f]
 //               affine; written head-major [4B][T][d*65] with flat index f*d + c (the order is internal: Q.K is
@@ -1097,6 +1368,37 @@ extern "C" int lh_emb_axis(const float* x, const void* wih_pk, const float* bih,
         hipLaunchKernelGGL(k_emb_lstm, dim3((nseq + 15) / 16, 2), dim3(256), 0, st, gx, (const _Float16*)whh_pk, hbuf, nseq, P);
         hipLaunchKernelGGL((k_emb_convt_res<false>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, hbuf,
                            (const _Float16*)wct_pk, bct, x, out, rows, P, T);
+    }
+    return check_launch();
+}
+
+// One axis path, round-4 form (see k_emb_rec): LayerNorm + split (k_emb_lnsplit) -> k_emb_rec (input GEMM + recurrence,
+// both directions in one launch) -> k_emb_convt2 (+ residual).  No gate pre-activation buffer.
+//   wrec_pk fp16 [2 dirs][8 waves][40 fragments][64 lanes][8] (embed_net.py pack_rec); brec [2][256] in (unit, gate) order,
+//   pre-scaled; wct_pk, bct as lh_emb_axis; xsplit scratch 2*B*T*65*64 fp16; hsplit scratch 2*nseq*P*128 fp16
+extern "C" int lh_emb_axis_fused(const float* x, const void* wrec_pk, const float* brec, const void* wct_pk, const float* bct,
+                                 void* xsplit, void* hsplit, float* out, int B, int T, int inter, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !wrec_pk || !brec || !wct_pk || !bct || !xsplit || !hsplit || !out || B <= 0 || T < EKS || x == out)
+        return LH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nseq = inter ? B * EF : B * T;
+    const int Lp = inter ? T : EF;
+    const int P = Lp - (EKS - 1);
+    const long rows = (long)B * T * EF;
+    const long lnb = (rows + 15) / 16;
+    const int ctiles = nseq * ((Lp + 63) / 64);
+    hipLaunchKernelGGL(k_emb_lnsplit, dim3((unsigned)(lnb < 4096 ? lnb : 4096)), dim3(256), 0, st, x, (_Float16*)xsplit, rows);
+    if (inter) {
+        hipLaunchKernelGGL((k_emb_rec<true>), dim3((nseq + 15) / 16, 2), dim3(ER_NT), 0, st, (const _Float16*)xsplit,
+                           (const _Float16*)wrec_pk, brec, (_Float16*)hsplit, nseq, P, T, rows);
+        hipLaunchKernelGGL((k_emb_convt2<true>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
+                           (const _Float16*)wct_pk, bct, x, out, nseq, P, T);
+    } else {
+        hipLaunchKernelGGL((k_emb_rec<false>), dim3((nseq + 15) / 16, 2), dim3(ER_NT), 0, st, (const _Float16*)xsplit,
+                           (const _Float16*)wrec_pk, brec, (_Float16*)hsplit, nseq, P, T, rows);
+        hipLaunchKernelGGL((k_emb_convt2<false>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
+                           (const _Float16*)wct_pk, bct, x, out, nseq, P, T);
     }
     return check_launch();
 }

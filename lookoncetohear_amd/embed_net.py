@@ -76,6 +76,10 @@ class EmbedTFGridNet(nn.Module):
         self.embed_proj = nn.Sequential(nn.Linear(self.n_freqs * 64, embed_dim), nn.LayerNorm(embed_dim))
         self._pack_key = None
         self._packed = None
+        # axis path: k_emb_rec (input GEMM inside the recurrence, round 4) or the round-1 three-kernel form with the gate
+        # pre-activations through HBM (LOOKONCE_EMB_FUSED=0; A/B runs)
+        import os
+        self.fused_axis = os.environ.get("LOOKONCE_EMB_FUSED", "1") != "0"
         self._lib_override = None          # TEST HOOK ONLY (tests/hipemu)
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: (C-ABI call, start event, end event) per launch
@@ -141,7 +145,7 @@ class EmbedTFGridNet(nn.Module):
             if taps is not None:
                 taps["z0"] = za.clone()
             P_i, P_e = F_ - 3, T - 3
-            gx = e(max(B * T * P_i, B * F_ * P_e) * 512)
+            gx = e(max(B * T * P_i, B * F_ * P_e) * 512) if not self.fused_axis else None
             hbuf = e(max(B * T * P_i, B * F_ * P_e) * 128)
             xsp = e(B, T, F_, C_)              # fp16 hi | lo images of the normalised axis input (same bytes as fp32)
             nb, Tp = self.n_head * B, (T + 63) // 64 * 64
@@ -151,10 +155,16 @@ class EmbedTFGridNet(nn.Module):
             vtb, scb, pb = h16(2 * nb * 1040 * Tp), e(nb * T * Tp), h16(2 * nb * T * Tp)
             for i in range(self.n_layers):
                 bp = pk["blocks"][i]
-                lib.call("lh_emb_axis", P(za), P(bp["intra_wih"]), P(bp["intra_bih"]), P(bp["intra_whh"]), P(bp["intra_wct"]),
-                         P(bp["intra_bct"]), P(xsp), P(gx), P(hbuf), P(zb), B, T, 0, st)
-                lib.call("lh_emb_axis", P(zb), P(bp["inter_wih"]), P(bp["inter_bih"]), P(bp["inter_whh"]), P(bp["inter_wct"]),
-                         P(bp["inter_bct"]), P(xsp), P(gx), P(hbuf), P(zc), B, T, 1, st)
+                if self.fused_axis:
+                    lib.call("lh_emb_axis_fused", P(za), P(bp["intra_wrec"]), P(bp["intra_brec"]), P(bp["intra_wct"]),
+                             P(bp["intra_bct"]), P(xsp), P(hbuf), P(zb), B, T, 0, st)
+                    lib.call("lh_emb_axis_fused", P(zb), P(bp["inter_wrec"]), P(bp["inter_brec"]), P(bp["inter_wct"]),
+                             P(bp["inter_bct"]), P(xsp), P(hbuf), P(zc), B, T, 1, st)
+                else:
+                    lib.call("lh_emb_axis", P(za), P(bp["intra_wih"]), P(bp["intra_bih"]), P(bp["intra_whh"]), P(bp["intra_wct"]),
+                             P(bp["intra_bct"]), P(xsp), P(gx), P(hbuf), P(zb), B, T, 0, st)
+                    lib.call("lh_emb_axis", P(zb), P(bp["inter_wih"]), P(bp["inter_bih"]), P(bp["inter_whh"]), P(bp["inter_wct"]),
+                             P(bp["inter_bct"]), P(xsp), P(gx), P(hbuf), P(zc), B, T, 1, st)
                 if taps is not None:
                     taps[f"blocks.{i}.x1"], taps[f"blocks.{i}.x2"] = zb.clone(), zc.clone()
                 lib.call("lh_emb_attn_block", P(zc), P(bp["wqkv"]), P(bp["bqkv"]), P(bp["slopes"]), P(bp["lnq_w"]),
@@ -184,6 +194,50 @@ def _pack_whh_f16x3(w_hh: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo], dim=4).contiguous()
 
 
+def pack_rec(sd, pre, ax):
+    """Weights of k_emb_rec (lh_embed.hip): the transposed gate GEMM's MFMA A fragments, fp16 hi | lo (lo un-rescaled),
+    [2 dirs][8 waves][40 fragments][64 lanes][8], fragment order per wave: tile j = 0, 1: { window slot k4 = 0..3:
+    k-step 0, 1: hi, lo } then { W_hh k-step 0, 1: hi, lo }.  Lane l holds row  gate*64 + unit  (gate = l & 3,
+    unit = 8 wave + 2 ((l & 15) >> 2) + j) at k = 32 ks + 8 (l >> 4) + e.  W_ih columns: channel k of window slot k4 =
+    espnet2's unfolded feature k*4 + tap with tap = k4 for the forward direction and 3 - k4 for the reverse one (the
+    kernel walks mirrored positions), times the LayerNorm gamma; rows times the gate's exponent factor (weights.py
+    gate_prescale).  Returns (image, bias [2][256] in (unit, gate) order with W_ih beta + b_ih + b_hh, same factor)."""
+    from .weights import gate_prescale
+    g = lambda k: sd[pre + k].double()
+    dev = sd[pre + f"{ax}_rnn.weight_ih_l0"].device
+    lw, lb = g(f"{ax}_norm.gamma").reshape(-1), g(f"{ax}_norm.beta").reshape(-1)
+    scale = gate_prescale(64, dev)                                                 # [256] rows gate*64 + unit
+    lane = torch.arange(64, device=dev)
+    m, q = lane & 15, lane >> 4
+    e = torch.arange(8, device=dev)
+    imgs, biases = [], []
+    for d, sfx in enumerate(("", "_reverse")):
+        w = g(f"{ax}_rnn.weight_ih_l0{sfx}").reshape(256, 64, 4)                   # [row, channel, tap]
+        b = (g(f"{ax}_rnn.bias_ih_l0{sfx}") + g(f"{ax}_rnn.bias_hh_l0{sfx}") + (w * lb[None, :, None]).sum((1, 2))) * scale
+        w = w * lw[None, :, None] * scale[:, None, None]
+        whh = g(f"{ax}_rnn.weight_hh_l0{sfx}") * scale[:, None]                    # [row, 64]
+        per_wave = []
+        for wave in range(8):
+            frags = []
+            for j in range(2):
+                row = (m & 3) * 64 + 8 * wave + 2 * (m >> 2) + j                   # [64 lanes]
+                for k4 in range(4):
+                    tap = k4 if d == 0 else 3 - k4
+                    for ks in range(2):
+                        kk = ks * 32 + q[:, None] * 8 + e[None, :]                 # [64, 8]
+                        v = w[row[:, None], kk, tap].float()
+                        hi, lo = split_f16(v)
+                        frags += [hi, lo]
+                for ks in range(2):
+                    kk = ks * 32 + q[:, None] * 8 + e[None, :]
+                    hi, lo = split_f16(whh[row[:, None], kk].float())
+                    frags += [hi, lo]
+            per_wave.append(torch.stack(frags))                                    # [40, 64, 8]
+        imgs.append(torch.stack(per_wave))
+        biases.append(b.reshape(4, 64).t().reshape(-1).float())                    # (unit, gate)
+    return torch.stack(imgs).contiguous(), torch.stack(biases).contiguous()
+
+
 def _pack_axis(sd, pre, ax):
     """Input GEMM of one axis path: both directions, LN affine folded, features reordered from espnet's unfold order
     (c*4 + k) to window-major (k*64 + c), output columns reordered to (direction, unit, gate)."""
@@ -203,6 +257,7 @@ def _pack_axis(sd, pre, ax):
         f"{ax}_wct": pack_linear_f16x3(sd[pre + f"{ax}_linear.weight"].permute(1, 2, 0).reshape(64, 512).float().contiguous()),
         f"{ax}_bct": sd[pre + f"{ax}_linear.bias"].float().contiguous(),
     }
+    out[f"{ax}_wrec"], out[f"{ax}_brec"] = pack_rec(sd, pre, ax)
     return out
 
 
