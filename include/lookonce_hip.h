@@ -168,7 +168,7 @@ int lh_intra_block(const float* x, const void* w_pk, const float* b_sum, const v
  * weights.py `inter_lin_wu`); blin [64]
  *   w_pk   [8 waves][2 tiles][4 ksteps][64 lanes][hi 8 | lo 8] fp16 (weights.py pack_lstm_f16x3_w8, `inter_w8`): the
  *          eight-wave kernel multiplies transposed (weights = MFMA A operand); lane l of (wave v, tile m, kstep ks)
- *          holds row gate*64 + unit of [W_ih * ln_w | W_hh], gate = (l & 15) & 3, unit = 8v + 4m + ((l & 15) >> 2),
+ *          holds row gate*64 + unit of [W_ih * ln_w | W_hh], gate = (l & 15) & 3, unit = 8v + 2 ((l & 15) >> 2) + m,
  *          at k = 32 ks + 8 (l >> 4) + j; lo unscaled, rows scaled by the gate's exponent factor;
  *   b_sum  [256] in PyTorch gate order (i, f, g, o) x 64, same scaling (weights.py `inter_b16`)
  */
@@ -282,9 +282,13 @@ int lh_emb_axis(const float* x, const void* wih_pk, const float* bih, const void
  *   wrec_pk  fp16 [2 dirs][8 waves][40 fragments][64 lanes][8]: MFMA A fragments of [W_ih (4 window slots) | W_hh], rows
  *            ordered (unit, gate), LayerNorm gamma and the gates' exponent factors folded in (embed_net.py pack_rec)
  *   brec     [2][256] in (unit, gate) order, same folding;  wct_pk, bct as lh_emb_axis
- *   xsplit   scratch 2*B*T*65*64 fp16;  hsplit scratch 2*nseq*P*128 fp16 (hi | lo images of the hidden states) */
+ *   xsplit   scratch 2*B*T*65*64 fp16;  hsplit scratch 2*nseq*P*128 fp16 (hi | lo images of the hidden states)
+ *   have_xsplit  non-zero: xsplit already holds the channel-normalised, split x (left there by the previous axis call's
+ *            emit_split or by lh_emb_attn_block's xsplit_next) and the normalisation launch is skipped
+ *   emit_split   non-zero: xsplit is overwritten with the normalised, split OUT rows once the recurrence has consumed it */
 int lh_emb_axis_fused(const float* x, const void* wrec_pk, const float* brec, const void* wct_pk, const float* bct,
-                      void* xsplit, void* hsplit, float* out, int B, int T, int inter, lh_stream_t stream);
+                      void* xsplit, void* hsplit, float* out, int B, int T, int inter, int have_xsplit, int emit_split,
+                      lh_stream_t stream);
 
 /* Enrollment embedder, attention branch of one GridNetBlock (espnet2 GridNetBlock.forward attention part, restated in
  * oracle/embedder_oracle.py:149-168): per-head Q/K/V 1x1 conv + PReLU + LayerNorm over (channel, bin), full T x T
@@ -297,12 +301,15 @@ int lh_emb_axis_fused(const float* x, const void* wrec_pk, const float* brec, co
  *   bqkv, slopes [128] (PReLU slope of each output column's head conv)
  *   lnq_*, lnk_* [4][520], lnv_* [4][1040]: LayerNorm affine re-ordered to (bin*d + channel)
  *   wproj_pk [4][2][64][16]; bproj [64]; slope_p [1]; lnp_* [4160] re-ordered to (bin*64 + channel)
+ *   xsplit_next  NULL, or 2*B*T*65*64 fp16: the channel-normalised, split `out` rows for the next block's intra axis call
+ *            (lh_emb_axis_fused have_xsplit)
  */
 int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const float* bqkv, const float* slopes,
                       const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
                       const float* lnv_w, const float* lnv_b, const void* wproj_pk, const float* bproj,
                       const float* slope_p, const float* lnp_w, const float* lnp_b, void* q, void* k, float* v,
-                      void* vt, float* sc, void* p, float* merged, float* out, int B, int T, lh_stream_t stream);
+                      void* vt, float* sc, void* p, float* merged, float* out, void* xsplit_next, int B, int T,
+                      lh_stream_t stream);
 
 /* Enrollment embedder head (reference src/models/tfgridnet_orig/tfgridnet.py:120-127): Linear(65*64 -> 256) per
  * frame, LayerNorm(256), mean over frames.

@@ -37,8 +37,8 @@ SIGNATURES = {
     "lh_deconv_istft": [_P] * 10 + [_I, _I, _P],
     "lh_emb_frontend": [_P] * 9 + [_I, _I, _I, _P],
     "lh_emb_axis": [_P] * 10 + [_I, _I, _I, _P],
-    "lh_emb_axis_fused": [_P] * 8 + [_I, _I, _I, _P],
-    "lh_emb_attn_block": [_P] * 23 + [_I, _I, _P],
+    "lh_emb_axis_fused": [_P] * 8 + [_I, _I, _I, _I, _I, _P],
+    "lh_emb_attn_block": [_P] * 24 + [_I, _I, _P],
     "lh_emb_head": [_P] * 7 + [_I, _I, _P],
     "lh_render_binaural": [_P] * 8 + [_I, _I, _I, _I, _P],
     "lh_metric_sums": [_P] * 8 + [_I, _I, _I, _P],

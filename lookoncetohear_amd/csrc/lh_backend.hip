@@ -24,7 +24,10 @@ constexpr int BE_SK = 7;                  // synthesis k-steps: 194 spectrum row
 constexpr int BE_SA = BE_SK * 4 * BE_NJ * 8;   // halves per source in the Sx A image
 constexpr int BE_FP = NFFT + 4;           // synthesis frame staging row
 constexpr int BE_NLD = (NF * 16 + BE_NT - 1) / BE_NT;   // float4 per thread and frame (4)
-constexpr int BE_RING = 4;                // input frames in flight per workgroup
+#if !defined(BE_RING_N)
+#define BE_RING_N 2
+#endif
+constexpr int BE_RING = BE_RING_N;        // input frames in flight per workgroup (2: no spills and 0.21 ms per call at B = 32; 4 = rounds 2-3: 22 spilled VGPRs with the range-safe staging, 0.23 ms — profiles/r04c)
 #if defined(LH_PROBE_TRACE)              // timing probe build only (scripts/probe_trace.py --backend): stamps of workgroup 3, tile 2 of its run
 __device__ unsigned long long lh_be_trace_buf[32];
 #if defined(LH_PROBE_TRACE_T1)           // streaming shape (B = 1, T = 1): the only workgroup, its only tile; 20 / 21 = kernel entry / prologue done
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     //     |D[td]| <= max|b| + 3 W1 (M[td] + M[td-1] + M[td-2]),   M[fr] = max |Y[fr]|,  W1 = max_col sum_c |Wd[col][c]|
     // (data-independent of the products, so no extra barrier); `sinv[jd]` undoes it on the synthesis accumulators.
     __shared__ __attribute__((aligned(16))) float rinv[2][FR_RP];
-    __shared__ float wmax[2][BE_NT / 64];            // per-wave maxima of the two frames being staged
+    __shared__ float wmax[2][32];                     // per 16-lane-group maxima (8 waves x 4) of the two frames being staged
     __shared__ float fmaxr[4];                        // M[fr] ring, slot (fr + 4) & 3 like the partial products
     __shared__ __attribute__((aligned(16))) float sinv[BE_NJ];
     __shared__ float w1s[48];
@@ -186,7 +189,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             __syncthreads();
             float m = wmax[0][0];
 #pragma unroll
-            for (int w = 1; w < BE_NT / 64; ++w) m = fmaxf(m, wmax[0][w]);
+            for (int w = 1; w < BE_NT / 64; ++w) m = fmaxf(m, wmax[0][w]);      // (entries 0..7 here; the frame staging uses all 32)
             float sc, iv;
             pow2_scale<12>(m, sc, iv);
             if (tid < NSRC * NK) put_sx(0, tid / NK, tid % NK, cv * sc);
@@ -257,8 +260,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                         tm[q] = stage_row(ahi + q * FR_A, alo + q * FR_A, rinv[q], tv + BE_NT * i, hv, tm[q]);
                     }
                 }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { const float wm = wave_max(tm[q]); if (lane == 0) wmax[q][wave] = wm; }
+                if (l15 == 0) { wmax[0][wave * 4 + g4] = tm[0]; wmax[1][wave * 4 + g4] = tm[1]; }   // (row maxima are group-uniform)
                 __syncthreads();
                 zero_guards();                        // the buffer ran over guard rows; the products below write rows 1..97 only
             } else {
@@ -268,15 +270,15 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                     tm[0] = stage_row(ahi, alo, rinv[0], tv + BE_NT * i, stg[u][i], tm[0]);
                     if (two) tm[1] = stage_row(ahi + FR_A, alo + FR_A, rinv[1], tv + BE_NT * i, stg[u + 1][i], tm[1]);
                 }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { const float wm = wave_max(tm[q]); if (lane == 0) wmax[q][wave] = wm; }
+                if (l15 == 0) { wmax[0][wave * 4 + g4] = tm[0]; wmax[1][wave * 4 + g4] = tm[1]; }   // (row maxima are group-uniform)
             }
             __syncthreads();
-            if (tid < 2 && (tid == 0 || two)) {        // M[fr + tid] for the spectrum bounds of frames fr + tid .. + 2
-                float m = wmax[tid][0];
-#pragma unroll
-                for (int w = 1; w < BE_NT / 64; ++w) m = fmaxf(m, wmax[tid][w]);
-                fmaxr[(fr + tid + 4) & 3] = m;
+            if (wave == 7) {                           // the one wave without a product tile: M[fr], M[fr + 1] for the spectrum
+#pragma unroll                                         // bounds of frames fr .. fr + 3, off the other waves' path
+                for (int q = 0; q < 2; ++q) {
+                    const float m = wave_max(lane < 32 ? wmax[q][lane] : 0.f);
+                    if (lane == 0 && (q == 0 || two)) fmaxr[(fr + q + 4) & 3] = m;
+                }
             }
             if (tr_it) BE_STAMP(12);
             // Refill the two ring slots UNCONDITIONALLY (frame index clamped to the tile: past its end the tile's last frame

@@ -2,6 +2,8 @@
 // Shapes are those of the reference configs/tsh.json: the kernels are specialised on them.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 #include "../../include/lookonce_hip.h"
 
 namespace lh {
@@ -193,6 +195,12 @@ __device__ __forceinline__ void pin_here(float4& v) {
     (void)v;
 #endif
 }
+
+// compile-time loops for hand-ordered instruction sequences (lh_recur.hip xp_zip, lh_embed.hip k_emb_rec): f(integral_constant<int, I>) for I < N
+template <class F, int... I>
+__device__ __forceinline__ void xp_sf(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void xp_for(F&& f) { xp_sf(f, std::make_integer_sequence<int, N>{}); }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LH_OK : LH_ERR_LAUNCH; }
 

@@ -280,28 +280,32 @@ __device__ __forceinline__ long pos_row(int s, int pk, int T) {
 
 // channel LayerNorm (no affine: folded into the packed input weights) + fp16 hi/lo split of every position row, once
 // per axis call: xs = [hi image rows*64 halves | lo image rows*64 halves]; 16 lanes per 256-byte row
+// one float4 (channels 4q .. 4q+3) of a 64-channel row held by 16 consecutive lanes; every lane of the group must call it
+__device__ __forceinline__ void ln_split_store(float4 u, _Float16* __restrict__ xh, _Float16* __restrict__ xl, long off, bool valid) {
+    const float mean = group16_sum(u.x + u.y + u.z + u.w) * (1.0f / C);
+    u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
+    const float var = group16_sum(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.0f / C);
+    const float rstd = rsqrtf(var + LN_EPS);
+    const float v[4] = {u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd};
+    f16x4 h4, l4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        _Float16 h, l;
+        split_hl(v[i], h, l);
+        h4[i] = h;
+        l4[i] = l;
+    }
+    if (valid) {
+        *reinterpret_cast<f16x4*>(&xh[off]) = h4;
+        *reinterpret_cast<f16x4*>(&xl[off]) = l4;
+    }
+}
 __global__ void __launch_bounds__(256) k_emb_lnsplit(const float* __restrict__ x, _Float16* __restrict__ xs, long rows) {
     const int tid = threadIdx.x, q = tid & 15;
     _Float16* xh = xs;
     _Float16* xl = xs + rows * C;
-    for (long r = (long)blockIdx.x * 16 + (tid >> 4); r < rows; r += (long)gridDim.x * 16) {
-        float4 u = *reinterpret_cast<const float4*>(&x[r * C + q * 4]);
-        const float mean = group16_sum(u.x + u.y + u.z + u.w) * (1.0f / C);
-        u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
-        const float var = group16_sum(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.0f / C);
-        const float rstd = rsqrtf(var + LN_EPS);
-        const float v[4] = {u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd};
-        f16x4 h4, l4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            _Float16 h, l;
-            split_hl(v[i], h, l);
-            h4[i] = h;
-            l4[i] = l;
-        }
-        *reinterpret_cast<f16x4*>(&xh[r * C + q * 4]) = h4;
-        *reinterpret_cast<f16x4*>(&xl[r * C + q * 4]) = l4;
-    }
+    for (long r = (long)blockIdx.x * 16 + (tid >> 4); r < rows; r += (long)gridDim.x * 16)
+        ln_split_store(*reinterpret_cast<const float4*>(&x[r * C + q * 4]), xh, xl, r * C + q * 4, true);
 }
 
 // Gx[s*P + p][chunk*128 ..] = W_ih' [xhat(s, p) | xhat(s, p+1) | xhat(s, p+2) | xhat(s, p+3)] + b'
@@ -585,6 +589,7 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
                                                       int P, int T, long rows_x) {
     __shared__ __attribute__((aligned(16))) _Float16 ring[ER_RING * ER_POS];
     __shared__ __attribute__((aligned(16))) _Float16 himg[2 * ER_POS];
+    __shared__ __attribute__((aligned(16))) float bsm[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
     const int dir = blockIdx.y, s0 = blockIdx.x * 16;
     const int L = P + EKS - 1;
@@ -611,56 +616,67 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
             }
         }
     }
-    // bias of this lane's rows: tile j, unit 8w + 2 g4 + j, gates 0..3 (accumulator rows 4 g4 + gate)
-    f32x4 bz[2];
+    // bias of this lane's rows (tile j: unit 8w + 2 g4 + j, gates 0..3 = accumulator rows 4 g4 + gate): kept in LDS and read
+    // into the x-half accumulators at the top of every step — 8 registers the 256-register budget does not have
+    if (tid < 256) bsm[tid] = bias[dir * 256 + tid];
+    const int b_off = (wave * 8 + 2 * g4) * 4;
+    auto bias_acc = [&](f32x4 (&acc)[2]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float4 b4 = *reinterpret_cast<const float4*>(&bias[dir * 256 + (wave * 8 + 2 * g4 + j) * 4]);
-        bz[j] = f32x4{b4.x, b4.y, b4.z, b4.w};
-    }
+        for (int j = 0; j < 2; ++j) {
+            const float4 b4 = *reinterpret_cast<const float4*>(&bsm[b_off + j * 4]);
+            acc[j] = f32x4{b4.x, b4.y, b4.z, b4.w};
+        }
+    };
 
     // row-wise roles.  Waves 0..3 stage positions: thread -> (sequence row, 16-byte piece: 0..7 of the hi image, 8..15 lo)
     const int rrow = (tid & 255) >> 4, piece = tid & 15;
     const int sq = min(s0 + rrow, nseq - 1);
     const bool loader = wave < 4;
-    const _Float16* xsrc = xs + (piece < 8 ? 0 : rows_x * C) + (piece & 7) * 8;
+    // position p of sequence sq sits at row pos_row(sq, 0) + p * (INTER ? 65 : 1): base pointer + stride, no index algebra
+    // in the loop
+    const _Float16* xsrc = xs + (piece < 8 ? 0 : rows_x * C) + (piece & 7) * 8 + pos_row<INTER>(sq, 0, T) * C;
+    const int pstride = (INTER ? EF : 1) * C;
     auto load_pos = [&](int pi) -> f16x8 {                    // processing-order position pi (clamped), mirrored for dir 1
         pi = min(pi, L - 1);
         const int p = dir ? L - 1 - pi : pi;
-        return *reinterpret_cast<const f16x8*>(&xsrc[pos_row<INTER>(sq, p, T) * C]);
+        return *reinterpret_cast<const f16x8*>(&xsrc[(long)p * pstride]);
     };
     auto put_pos = [&](int pi, const f16x8& v) {
         *reinterpret_cast<f16x8*>(&ring[(pi & (ER_RING - 1)) * ER_POS + rrow * ER_RP + piece * 8]) = v;
     };
     // waves 4..7 write the hidden states of the previous step: himg row -> hi | lo images, this direction's 64 columns
-    _Float16* hdst = hs + (piece < 8 ? 0 : hrows * 128) + dir * H + (piece & 7) * 8;
+    _Float16* hdst = hs + (piece < 8 ? 0 : hrows * 128) + dir * H + (piece & 7) * 8 + (long)(s0 + rrow) * P * 128;
+    const bool hvalid = s0 + rrow < nseq;
     auto flush_h = [&](int it, int buf) {                     // h of processing step it
-        if (s0 + rrow < nseq) {
+        if (hvalid) {
             const int t = dir ? P - 1 - it : it;
-            *reinterpret_cast<f16x8*>(&hdst[((long)(s0 + rrow) * P + t) * 128]) =
+            *reinterpret_cast<f16x8*>(&hdst[(long)t * 128]) =
                 *reinterpret_cast<const f16x8*>(&himg[buf * ER_POS + rrow * ER_RP + piece * 8]);
         }
     };
 
-    // x half of the gates of processing step `it`: bias + sum over the 4 window slots (ring positions it .. it+3)
+    // x half of the gates of processing step `it`: bias + sum over the 4 window slots (ring positions it .. it+3), as 8
+    // groups (slot k4, k-step ks) of 6 MFMAs; x_frag(g) reads the group's B fragments
     const int frag_off = l15 * ER_RP + g4 * 8;
-    auto gate_x = [&](int it, f32x4 (&out)[2]) {
-        f32x4 am[2] = {bz[0], bz[1]}, ac[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto x_frag = [&](int it, int g, f16x8& xh, f16x8& xl) {
+        const _Float16* base = &ring[((it + (g >> 1)) & (ER_RING - 1)) * ER_POS + frag_off + (g & 1) * 32];
+        xh = *reinterpret_cast<const f16x8*>(base);
+        xl = *reinterpret_cast<const f16x8*>(base + 64);
+    };
+    auto gate_x = [&](int it, f32x4 (&out)[2]) {             // plain form (prologue)
+        f32x4 am[2], ac[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        bias_acc(am);
+        xp_for<8>([&](auto g_) {
+            constexpr int g = decltype(g_)::value, k4 = g >> 1, ks = g & 1;
+            f16x8 xh, xl;
+            x_frag(it, g, xh, xl);
 #pragma unroll
-        for (int k4 = 0; k4 < EKS; ++k4) {
-            const _Float16* base = &ring[((it + k4) & (ER_RING - 1)) * ER_POS + frag_off];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(base + ks * 32);
-                const f16x8 xl = *reinterpret_cast<const f16x8*>(base + 64 + ks * 32);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    am[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxh[j][k4][ks], xh, am[j], 0, 0, 0);
-                    ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxh[j][k4][ks], xl, ac[j], 0, 0, 0);
-                    ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxl[j][k4][ks], xh, ac[j], 0, 0, 0);
-                }
+            for (int j = 0; j < 2; ++j) {
+                am[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxh[j][k4][ks], xh, am[j], 0, 0, 0);
+                ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxh[j][k4][ks], xl, ac[j], 0, 0, 0);
+                ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxl[j][k4][ks], xh, ac[j], 0, 0, 0);
             }
-        }
+        });
 #pragma unroll
         for (int j = 0; j < 2; ++j) out[j] = f32x4{am[j][0] + ac[j][0], am[j][1] + ac[j][1], am[j][2] + ac[j][2], am[j][3] + ac[j][3]};
     };
@@ -683,38 +699,90 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
     f32x4 gxn[2];
     gate_x(0, gxn);
 
+    // One step, hand-ordered (hipcc's own schedule ran all 60 MFMAs, then the ~75 vector instructions of the two cell
+    // updates with the matrix pipe idle, then the barrier: 3300 cycles per step against 2040 of MFMA issue for the two waves
+    // of a SIMD).  Order: h fragments + first x group issued -> x group 0 (6 MFMAs, off the chain, while the h reads land)
+    // -> the 12 MFMAs on the chain -> x groups 1..7 (42 MFMAs), each MFMA followed by one slice of the cell update and a
+    // scheduling fence, the next group's fragments read one group ahead.
     auto step = [&](int it, f16x8& stg) {
         const int cur = it & 1;
-        // on the chain: gates = x half (computed one step ago) + W_hh h_{it-1}
-        f32x4 am[2] = {gxn[0], gxn[1]}, ac[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const bool more = it + 1 < P;                     // (the last step still runs the x half: its result is dropped)
+        f16x8 hh[2], hl[2], xh[2], xl[2];
         {
             const _Float16* base = &himg[cur * ER_POS + frag_off];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const f16x8 hh = *reinterpret_cast<const f16x8*>(base + ks * 32);
-                const f16x8 hl = *reinterpret_cast<const f16x8*>(base + 64 + ks * 32);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    am[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whh[j][ks], hh, am[j], 0, 0, 0);
-                    ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whh[j][ks], hl, ac[j], 0, 0, 0);
-                    ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whl[j][ks], hh, ac[j], 0, 0, 0);
-                }
+                hh[ks] = *reinterpret_cast<const f16x8*>(base + ks * 32);
+                hl[ks] = *reinterpret_cast<const f16x8*>(base + 64 + ks * 32);
             }
         }
-        // off the chain: the x half of step it + 1 (window slots = positions it+1 .. it+4, staged >= 1 barrier ago)
-        if (it + 1 < P) gate_x(it + 1, gxn);
-        // cell update: two adjacent units of sequence l15 per lane
-        float hv[2];
+        x_frag(it + 1, 0, xh[0], xl[0]);
+        f32x4 am[2] = {gxn[0], gxn[1]}, ac[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // on the chain
+        f32x4 xm[2], xc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};                          // x half of step it + 1
+        bias_acc(xm);
+        // cell update of the two units of this lane, cut into 29 slices (lstm_cell_pre's arithmetic, same operation order)
+        float a[2][4], r[2][4], g2[2], cc[2], hv[2];
+        _Float16 sh_[2], sl_[2];
+        auto cell_op = [&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            if constexpr (k >= 0 && k < 26) {
+                constexpr int j = k / 13, o = k % 13;
+                if constexpr (o == 0) { a[j][0] = am[j][0] + ac[j][0]; a[j][1] = am[j][1] + ac[j][1]; }
+                if constexpr (o == 1) { a[j][2] = am[j][2] + ac[j][2]; a[j][3] = am[j][3] + ac[j][3]; }
+                if constexpr (o == 2) { a[j][0] = __builtin_amdgcn_exp2f(a[j][0]); a[j][1] = __builtin_amdgcn_exp2f(a[j][1]); }
+                if constexpr (o == 3) { a[j][2] = __builtin_amdgcn_exp2f(a[j][2]); a[j][3] = __builtin_amdgcn_exp2f(a[j][3]); }
+                if constexpr (o == 4) { a[j][0] = 1.0f + a[j][0]; a[j][1] = 1.0f + a[j][1]; }
+                if constexpr (o == 5) { a[j][2] = 1.0f + a[j][2]; a[j][3] = 1.0f + a[j][3]; }
+                if constexpr (o == 6) { r[j][0] = __builtin_amdgcn_rcpf(a[j][0]); r[j][1] = __builtin_amdgcn_rcpf(a[j][1]); }
+                if constexpr (o == 7) { r[j][2] = __builtin_amdgcn_rcpf(a[j][2]); r[j][3] = __builtin_amdgcn_rcpf(a[j][3]); }
+                if constexpr (o == 8) { g2[j] = 2.0f * r[j][2] - 1.0f; }
+                if constexpr (o == 9) { cc[j] = r[j][1] * creg[j] + r[j][0] * g2[j]; creg[j] = cc[j]; }
+                if constexpr (o == 10) { cc[j] = __builtin_amdgcn_exp2f(-2.0f * LOG2E * cc[j]); }
+                if constexpr (o == 11) { cc[j] = __builtin_amdgcn_rcpf(1.0f + cc[j]); }
+                if constexpr (o == 12) { hv[j] = r[j][3] * (2.0f * cc[j] - 1.0f); }
+            }
+            if constexpr (k == 26) split_hl(hv[0], sh_[0], sl_[0]);
+            if constexpr (k == 27) split_hl(hv[1], sh_[1], sl_[1]);
+            if constexpr (k == 28) {
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                _Float16* hrow = &himg[(cur ^ 1) * ER_POS + l15 * ER_RP + wave * 8 + 2 * g4];
+                *reinterpret_cast<f16x2*>(hrow) = f16x2{sh_[0], sh_[1]};
+                *reinterpret_cast<f16x2*>(hrow + 64) = f16x2{sl_[0], sl_[1]};
+            }
+        };
+        auto x_group = [&](auto g_, auto zip_) {          // 6 MFMAs of group g; with zip: cell slice + fence after each
+            constexpr int g = decltype(g_)::value, k4 = g >> 1, ks = g & 1, b = g & 1;
+            constexpr bool zip = decltype(zip_)::value;
+            if constexpr (g + 1 < 8) x_frag(it + 1, g + 1, xh[b ^ 1], xl[b ^ 1]);
+            xp_for<6>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, j = i / 3, pr = i % 3;
+                if constexpr (pr == 0) xm[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxh[j][k4][ks], xh[b], xm[j], 0, 0, 0);
+                if constexpr (pr == 1) xc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxh[j][k4][ks], xl[b], xc[j], 0, 0, 0);
+                if constexpr (pr == 2) xc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxl[j][k4][ks], xh[b], xc[j], 0, 0, 0);
+                if constexpr (zip) {
+                    constexpr int slot = (g - 1) * 6 + i;                  // 0 .. 41
+                    cell_op(std::integral_constant<int, slot - 6>{});      // the chain's results are ~6 MFMAs old by then
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        };
+        x_group(std::integral_constant<int, 0>{}, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            lstm_cell_pre(am[j][0] + ac[j][0], am[j][1] + ac[j][1], am[j][2] + ac[j][2], am[j][3] + ac[j][3], creg[j], hv[j]);
-        _Float16 h0, l0, h1, l1;
-        split_hl(hv[0], h0, l0);
-        split_hl(hv[1], h1, l1);
-        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-        _Float16* hrow = &himg[(cur ^ 1) * ER_POS + l15 * ER_RP + wave * 8 + 2 * g4];
-        *reinterpret_cast<f16x2*>(hrow) = f16x2{h0, h1};
-        *reinterpret_cast<f16x2*>(hrow + 64) = f16x2{l0, l1};
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                am[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whh[j][ks], hh[ks], am[j], 0, 0, 0);
+                ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whh[j][ks], hl[ks], ac[j], 0, 0, 0);
+                ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whl[j][ks], hh[ks], ac[j], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        xp_for<7>([&](auto g_) { x_group(std::integral_constant<int, decltype(g_)::value + 1>{}, std::true_type{}); });
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                gxn[j] = f32x4{xm[j][0] + xc[j][0], xm[j][1] + xc[j][1], xm[j][2] + xc[j][2], xm[j][3] + xc[j][3]};
+        }
         if (loader) {                                    // position it + 6 (loaded two steps ago) -> ring; fetch it + 8
             put_pos(it + 6, stg);
             stg = load_pos(it + 8);
@@ -736,17 +804,26 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
 // fp16 hi | lo hidden-state images.  One tile = 64 consecutive output positions of ONE sequence: its 67 rows of h are
 // staged once (16-byte copies, no conversion; zero rows outside 0..P-1) and the transposed conv's taps are row offsets
 // in the A-fragment address (k-step ks covers tap ks / 4, hidden columns 32 (ks & 3) ..), like k_emb_gx's unfold.
-constexpr int CT_RP = 69;                          // odd row pitch in 16-byte slots
-constexpr int CT_ROWS = 64 + EKS - 1;              // 67
-constexpr int CT_NLD = (CT_ROWS * 16 + 255) / 256; // 16-byte pieces per thread and image (5)
+template <bool INTER>
+struct CtShape {                                   // 16-row MFMA tiles per workgroup tile: the intra axis has 65 positions per
+    static constexpr int MT = INTER ? 4 : 5;       // sequence — one tile of 80 (5 row tiles) instead of 64 + 1 (8 row tiles)
+    static constexpr int RT = 16 * MT;             // output positions per tile
+    static constexpr int ROWS = RT + EKS - 1;      // staged h rows
+    static constexpr int RP = ROWS | 1;            // odd row pitch in 16-byte slots
+    static constexpr int NLD = (ROWS * 16 + 255) / 256;
+};
 template <bool INTER>
 __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restrict__ hs, const _Float16* __restrict__ w_pk,
                                                        const float* __restrict__ bias, const float* __restrict__ x,
-                                                       float* __restrict__ out, int nseq, int P, int T) {
-    constexpr int KS = 16, CSP = C + 4;
-    __shared__ __attribute__((aligned(16))) _Float16 ahi[16 * CT_RP * 8];
-    __shared__ __attribute__((aligned(16))) _Float16 alo[16 * CT_RP * 8];
-    __shared__ __attribute__((aligned(16))) float cs[64 * CSP];
+                                                       float* __restrict__ out, _Float16* __restrict__ xs_next, long rows_x,
+                                                       int nseq, int P, int T) {
+    // xs_next != NULL: the rows also leave channel-normalised and split (k_emb_lnsplit's images) for the NEXT axis pass, whose
+    // own normalisation launch (a read + a write of the whole activation) then drops out
+    using S = CtShape<INTER>;
+    constexpr int KS = 16, CSP = C + 4, MT = S::MT, RT = S::RT, ROWS = S::ROWS, RP = S::RP, NLD = S::NLD;
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[16 * RP * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[16 * RP * 8];
+    __shared__ __attribute__((aligned(16))) float cs[RT * CSP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
     f16x8 wh[KS], wl[KS];
 #pragma unroll
@@ -757,17 +834,17 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
     }
     const float bz = bias[wave * 16 + l15];
     const int L = P + EKS - 1;
-    const int tps = (L + 63) / 64;
+    const int tps = (L + RT - 1) / RT;
     const int ntiles = nseq * tps;
     const long hrows = (long)nseq * P;
     const _Float16* hh = hs;
     const _Float16* hl = hs + hrows * 128;
-    f16x8 sh[CT_NLD], sl[CT_NLD];
+    f16x8 sh[NLD], sl[NLD];
     auto fetch = [&](int tile) {
-        const int s = tile / tps, q0 = (tile % tps) * 64;
+        const int s = tile / tps, q0 = (tile % tps) * RT;
 #pragma unroll
-        for (int i = 0; i < CT_NLD; ++i) {
-            const int e = min(tid + 256 * i, CT_ROWS * 16 - 1);
+        for (int i = 0; i < NLD; ++i) {
+            const int e = min(tid + 256 * i, ROWS * 16 - 1);
             const int p = q0 - (EKS - 1) + (e >> 4);
             sh[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             sl[i] = sh[i];
@@ -780,13 +857,13 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int s = tile / tps, q0 = (tile % tps) * 64;
-        const int valid = min(64, L - q0);
+        const int s = tile / tps, q0 = (tile % tps) * RT;
+        const int valid = min(RT, L - q0);
 #pragma unroll
-        for (int i = 0; i < CT_NLD; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const int e = tid + 256 * i;
-            if (e < CT_ROWS * 16) {
-                const int idx = ((e & 15) * CT_RP + (e >> 4)) * 8;
+            if (e < ROWS * 16) {
+                const int idx = ((e & 15) * RP + (e >> 4)) * 8;
                 *reinterpret_cast<f16x8*>(&ahi[idx]) = sh[i];
                 *reinterpret_cast<f16x8*>(&alo[idx]) = sl[i];
             }
@@ -794,12 +871,13 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 #pragma unroll 1
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
+            if (m * 16 >= valid) break;                  // (workgroup-uniform) row tiles past the sequence's last position
             f32x4 am = f32x4{bz, bz, bz, bz}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 // output row m*16 + l15 = position q0 + that; tap k = ks >> 2 reads h row q - k = staged row (.. + 3 - k)
-                const int idx = (((ks & 3) * 4 + g4) * CT_RP + m * 16 + l15 + (EKS - 1) - (ks >> 2)) * 8;
+                const int idx = (((ks & 3) * 4 + g4) * RP + m * 16 + l15 + (EKS - 1) - (ks >> 2)) * 8;
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
                 am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
@@ -811,14 +889,15 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
             const int e = tid + 256 * i, rr = e >> 4, c4 = e & 15;
-            if (rr < valid) {
-                const long r = pos_row<INTER>(s, q0 + rr, T);
-                const float4 cv = *reinterpret_cast<const float4*>(&cs[rr * CSP + c4 * 4]);
-                const float4 xv = *reinterpret_cast<const float4*>(&x[r * C + c4 * 4]);
-                *reinterpret_cast<float4*>(&out[r * C + c4 * 4]) = make_float4(cv.x + xv.x, cv.y + xv.y, cv.z + xv.z, cv.w + xv.w);
-            }
+            const bool ok = rr < valid;                  // (uniform over the 16 lanes of a row)
+            const long r = pos_row<INTER>(s, q0 + (ok ? rr : 0), T);
+            const float4 cv = *reinterpret_cast<const float4*>(&cs[rr * CSP + c4 * 4]);
+            const float4 xv = *reinterpret_cast<const float4*>(&x[r * C + c4 * 4]);
+            const float4 ov = make_float4(cv.x + xv.x, cv.y + xv.y, cv.z + xv.z, cv.w + xv.w);
+            if (ok) *reinterpret_cast<float4*>(&out[r * C + c4 * 4]) = ov;
+            if (xs_next) ln_split_store(ov, xs_next, xs_next + rows_x * C, r * C + c4 * 4, ok);
         }
     }
 }
@@ -958,7 +1037,8 @@ __global__ void __launch_bounds__(256, 2) k_emb_qkv(const float* __restrict__ y,
 __global__ void __launch_bounds__(256, 2) k_emb_proj(const float* __restrict__ merged, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slope,
                                                      const float* __restrict__ lnw, const float* __restrict__ lnb,
-                                                     const float* __restrict__ y2, float* __restrict__ out, int nframes) {
+                                                     const float* __restrict__ y2, float* __restrict__ out,
+                                                     _Float16* __restrict__ xs_next, int nframes) {
     constexpr int YP = C + 4, N = EF * C, N4 = N / 4, NSLOT = (N4 + 255) / 256;     // 1040 float4 -> 5 slots
     __shared__ __attribute__((aligned(16))) _Float16 ahi[EFR_A];
     __shared__ __attribute__((aligned(16))) _Float16 alo[EFR_A];
@@ -1019,14 +1099,15 @@ __global__ void __launch_bounds__(256, 2) k_emb_proj(const float* __restrict__ m
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) {
             const int i = tid + 256 * k;
-            if (i < N4) {
-                float4 o;
-                o.x = rv[k].x + (vv[k].x - mean) * rstd * pw[k].x + pb[k].x;
-                o.y = rv[k].y + (vv[k].y - mean) * rstd * pw[k].y + pb[k].y;
-                o.z = rv[k].z + (vv[k].z - mean) * rstd * pw[k].z + pb[k].z;
-                o.w = rv[k].w + (vv[k].w - mean) * rstd * pw[k].w + pb[k].w;
-                *reinterpret_cast<float4*>(&out[fr + i * 4]) = o;
-            }
+            const bool ok = i < N4;                      // (uniform over the 16 lanes of a bin's row: N4 = 65 * 16)
+            float4 o;
+            o.x = rv[k].x + (vv[k].x - mean) * rstd * pw[k].x + pb[k].x;
+            o.y = rv[k].y + (vv[k].y - mean) * rstd * pw[k].y + pb[k].y;
+            o.z = rv[k].z + (vv[k].z - mean) * rstd * pw[k].z + pb[k].z;
+            o.w = rv[k].w + (vv[k].w - mean) * rstd * pw[k].w + pb[k].w;
+            if (ok) *reinterpret_cast<float4*>(&out[fr + i * 4]) = o;
+            // the next block's intra pass reads these rows channel-normalised and split: emit that form here too
+            if (xs_next) ln_split_store(o, xs_next, xs_next + (long)nframes * N, fr + (long)min(i, N4 - 1) * 4, ok);
         }
     }
 }
@@ -1192,6 +1273,63 @@ __global__ void __launch_bounds__(256) k_emb_softmax(const float* __restrict__ s
         split_hl(x, h, l);
         ph[i] = h;
         pl[i] = l;
+    }
+}
+
+// The same softmax with the row held in registers (round 4): one wave per row, NC float4 per lane (Tp <= 256 NC), ONE pass
+// over the scores (16-byte loads) and 8-byte hi / lo stores — the three-pass form above read every score three times with
+// 4-byte loads and wrote 2-byte stores (1.46 ms per call at B = 64, 2.2 TB/s for 3.3 GB).  Same arithmetic and operation
+// order per element (max, __expf(x - max), sum, product with 1 / sum).
+template <int NC>
+__global__ void __launch_bounds__(256) k_emb_softmax_reg(const float* __restrict__ sc, _Float16* __restrict__ p, long rows, int T,
+                                                         int Tp, long img) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = sc + row * Tp;
+    float v[NC][4];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i0 = (c * 64 + lane) * 4;
+        float4 u = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+        if (i0 < Tp) u = *reinterpret_cast<const float4*>(&sr[i0]);          // (columns T .. Tp-1 of the buffer are never written)
+        v[c][0] = i0 + 0 < T ? u.x : -3.0e38f; v[c][1] = i0 + 1 < T ? u.y : -3.0e38f;
+        v[c][2] = i0 + 2 < T ? u.z : -3.0e38f; v[c][3] = i0 + 3 < T ? u.w : -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, v[c][j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    // per-lane partial sums in the three-pass kernel's order: element i belongs to lane i % 64 there, to lane (i / 4) % 64 here —
+    // the sum is re-associated (fp32, 1251 terms in [0, 1]: 1e-7 relative), the products are not
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = (c * 64 + lane) * 4 + j;
+            v[c][j] = i < T ? __expf(v[c][j] - mx) : 0.f;
+            sum += v[c][j];
+        }
+    const float inv = 1.0f / wave_sum(sum);
+    _Float16* ph = p + row * Tp;
+    _Float16* pl = ph + img;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i0 = (c * 64 + lane) * 4;
+        if (i0 < Tp) {
+            f16x4 h4, l4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 h, l;
+                split_hl(v[c][j] * inv, h, l);
+                h4[j] = h;
+                l4[j] = l;
+            }
+            *reinterpret_cast<f16x4*>(&ph[i0]) = h4;
+            *reinterpret_cast<f16x4*>(&pl[i0]) = l4;
+        }
     }
 }
 
@@ -1376,8 +1514,12 @@ extern "C" int lh_emb_axis(const float* x, const void* wih_pk, const float* bih,
 // both directions in one launch) -> k_emb_convt2 (+ residual).  No gate pre-activation buffer.
 //   wrec_pk fp16 [2 dirs][8 waves][40 fragments][64 lanes][8] (embed_net.py pack_rec); brec [2][256] in (unit, gate) order,
 //   pre-scaled; wct_pk, bct as lh_emb_axis; xsplit scratch 2*B*T*65*64 fp16; hsplit scratch 2*nseq*P*128 fp16
+//   have_xsplit: xsplit already holds LayerNorm(x) split (written by the previous call with emit_split, or by
+//   lh_emb_attn_block's xsplit_next) — the normalisation launch is skipped;  emit_split: after the recurrence has consumed
+//   xsplit, the transposed-conv kernel overwrites it with LayerNorm(out) split, for the next axis call
 extern "C" int lh_emb_axis_fused(const float* x, const void* wrec_pk, const float* brec, const void* wct_pk, const float* bct,
-                                 void* xsplit, void* hsplit, float* out, int B, int T, int inter, lh_stream_t stream) {
+                                 void* xsplit, void* hsplit, float* out, int B, int T, int inter, int have_xsplit,
+                                 int emit_split, lh_stream_t stream) {
     using namespace lh;
     if (!x || !wrec_pk || !brec || !wct_pk || !bct || !xsplit || !hsplit || !out || B <= 0 || T < EKS || x == out)
         return LH_ERR_ARG;
@@ -1387,18 +1529,21 @@ extern "C" int lh_emb_axis_fused(const float* x, const void* wrec_pk, const floa
     const int P = Lp - (EKS - 1);
     const long rows = (long)B * T * EF;
     const long lnb = (rows + 15) / 16;
-    const int ctiles = nseq * ((Lp + 63) / 64);
-    hipLaunchKernelGGL(k_emb_lnsplit, dim3((unsigned)(lnb < 4096 ? lnb : 4096)), dim3(256), 0, st, x, (_Float16*)xsplit, rows);
+    const int rt = inter ? CtShape<true>::RT : CtShape<false>::RT;
+    const int ctiles = nseq * ((Lp + rt - 1) / rt);
+    if (!have_xsplit)
+        hipLaunchKernelGGL(k_emb_lnsplit, dim3((unsigned)(lnb < 4096 ? lnb : 4096)), dim3(256), 0, st, x, (_Float16*)xsplit, rows);
+    _Float16* xs_next = emit_split ? (_Float16*)xsplit : nullptr;
     if (inter) {
         hipLaunchKernelGGL((k_emb_rec<true>), dim3((nseq + 15) / 16, 2), dim3(ER_NT), 0, st, (const _Float16*)xsplit,
                            (const _Float16*)wrec_pk, brec, (_Float16*)hsplit, nseq, P, T, rows);
         hipLaunchKernelGGL((k_emb_convt2<true>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
-                           (const _Float16*)wct_pk, bct, x, out, nseq, P, T);
+                           (const _Float16*)wct_pk, bct, x, out, xs_next, rows, nseq, P, T);
     } else {
         hipLaunchKernelGGL((k_emb_rec<false>), dim3((nseq + 15) / 16, 2), dim3(ER_NT), 0, st, (const _Float16*)xsplit,
                            (const _Float16*)wrec_pk, brec, (_Float16*)hsplit, nseq, P, T, rows);
         hipLaunchKernelGGL((k_emb_convt2<false>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
-                           (const _Float16*)wct_pk, bct, x, out, nseq, P, T);
+                           (const _Float16*)wct_pk, bct, x, out, xs_next, rows, nseq, P, T);
     }
     return check_launch();
 }
@@ -1415,7 +1560,7 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
                                  const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
                                  const float* lnv_w, const float* lnv_b, const void* wproj_pk, const float* bproj,
                                  const float* slope_p, const float* lnp_w, const float* lnp_b, void* q, void* k, float* v,
-                                 void* vt, float* sc, void* p, float* merged, float* out, int B, int T,
+                                 void* vt, float* sc, void* p, float* merged, float* out, void* xsplit_next, int B, int T,
                                  lh_stream_t stream) {
     using namespace lh;
     if (!y2 || !wqkv_pk || !bqkv || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !wproj_pk ||
@@ -1433,12 +1578,28 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
                        EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
                        1.0f / sqrtf((float)EDQK), nb, tm, tm, B, T);
     const long rows = (long)nb * T;
-    hipLaunchKernelGGL(k_emb_softmax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sc, (_Float16*)p, rows, T, Tp, img_p);
+    {
+        const dim3 sg((unsigned)((rows + 3) / 4)), sb(256);
+        const int nc = (Tp + 255) / 256;             // float4 per lane with the row in registers (clips up to ~8 s: nc <= 8)
+#define LH_SOFTMAX_REG(NC_) hipLaunchKernelGGL((k_emb_softmax_reg<NC_>), sg, sb, 0, st, sc, (_Float16*)p, rows, T, Tp, img_p)
+        switch (nc) {
+            case 1: LH_SOFTMAX_REG(1); break;
+            case 2: LH_SOFTMAX_REG(2); break;
+            case 3: LH_SOFTMAX_REG(3); break;
+            case 4: LH_SOFTMAX_REG(4); break;
+            case 5: LH_SOFTMAX_REG(5); break;
+            case 6: LH_SOFTMAX_REG(6); break;
+            case 7: LH_SOFTMAX_REG(7); break;
+            case 8: LH_SOFTMAX_REG(8); break;
+            default: hipLaunchKernelGGL(k_emb_softmax, sg, sb, 0, st, sc, (_Float16*)p, rows, T, Tp, img_p);   // longer clips: three passes
+        }
+#undef LH_SOFTMAX_REG
+    }
     const int tn = (EDV + 127) / 128;
     hipLaunchKernelGGL((k_gemm_nt<1>), dim3(nb8 * tm * tn), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt, merged, T,
                        EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn, B, T);
     hipLaunchKernelGGL(k_emb_proj, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, st, merged, (const _Float16*)wproj_pk,
-                       bproj, slope_p, lnp_w, lnp_b, y2, out, nframes);
+                       bproj, slope_p, lnp_w, lnp_b, y2, out, (_Float16*)xsplit_next, nframes);
     return check_launch();
 }
 

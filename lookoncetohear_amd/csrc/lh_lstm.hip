@@ -746,7 +746,7 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
     const int g4 = lane >> 4, l15 = lane & 15;
     const bool lin_wave = wave < 4;
     const int q = tid & 15, rrow = (tid & 255) >> 4;
-    const int unit0 = 8 * wave + g4;
+    const int unit0 = 8 * wave + 2 * g4;             // adjacent units per lane (tile m = even / odd units): weights.py pack_lstm_f16x3_w8
 
     auto row_of0 = [&](int s) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si; };
     const long wg_row0 = row_of0(min(s0, nseq - 1));
@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bias[m][g] = b_sum[dir * 256 + g * 64 + unit0 + 4 * m];
+        for (int g = 0; g < 4; ++g) bias[m][g] = b_sum[dir * 256 + g * 64 + unit0 + m];
 
     const int a_frag = l15 * LH_AP + g4 * 8;
     const int a_cell = l15 * LH_AP + C + unit0;
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
         const int s = min(s0 + l15, nseq - 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            creg[m] = c0 ? c0[(long)s * H + unit0 + 4 * m] : 0.0f;
+            creg[m] = c0 ? c0[(long)s * H + unit0 + m] : 0.0f;
             hreg[m] = 0.0f;
         }
     }
@@ -903,8 +903,8 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
                 lstm_cell_pre(acc[m][0], acc[m][1], acc[m][2], acc[m][3], creg[m], hreg[m]);
                 _Float16 th, tl;
                 split_f16(hreg[m], th, tl);
-                ahi[nxt * NS * LH_AP + a_cell + 4 * m] = th;
-                alo[nxt * NS * LH_AP + a_cell + 4 * m] = tl;
+                ahi[nxt * NS * LH_AP + a_cell + m] = th;
+                alo[nxt * NS * LH_AP + a_cell + m] = tl;
             }
         };
         if (LIN) {
@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
     }
     if (hN) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) hf[l15 * LSP + unit0 + 4 * m] = hreg[m];
+        for (int m = 0; m < 2; ++m) hf[l15 * LSP + unit0 + m] = hreg[m];
     }
     __syncthreads();
     if (lin_wave) {
@@ -975,7 +975,7 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
     }
     if (cN && s0 + l15 < nseq) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + 4 * m] = creg[m];
+        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + m] = creg[m];
     }
 }
 

@@ -37,11 +37,7 @@ constexpr int XP_AP = 144;      // fp16 elements per LDS row: [x 64 | h 64] + 16
 constexpr int XP_LSP = 68;      // fp32 projection rows: 64 + 4 pad
 constexpr float XP_K2 = -2.0f * LOG2E;
 
-// compile-time loop / zipper helpers
-template <class F, int... I>
-__device__ __forceinline__ void xp_sf(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void xp_for(F&& f) { xp_sf(f, std::make_integer_sequence<int, N>{}); }
+// compile-time loop helpers xp_for / xp_sf: lh_common.h (shared with the embedder's recurrent kernel)
 // slot i of NSLOT: mf(i), then operations [i*NOPS/NSLOT, (i+1)*NOPS/NSLOT) of the tuple `ops`, then a scheduling fence
 template <int NSLOT, class MF, class Ops>
 __device__ __forceinline__ void xp_zip(MF& mf, Ops& ops) {
@@ -460,7 +456,10 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     const int g4 = lane >> 4, l15 = lane & 15;
     const bool lin_wave = wave < 4;
     const int q = tid & 15, rrow = (tid & 255) >> 4;
-    const int unit0 = 8 * wave + g4;
+    // a lane's two cells are ADJACENT units 8w + 2 g4 + m (tile m holds the even / odd units of the wave: weights.py
+    // pack_lstm_f16x3_w8), so h leaves as ONE 4-byte LDS store per half instead of two 2-byte stores 8 bytes apart (the 2-byte
+    // stores were 4-way bank conflicts on the 288-byte row stride: SQ_LDS_BANK_CONFLICT 0.34 of the LDS cycles in round 3)
+    const int unit0 = 8 * wave + 2 * g4;
 
     auto row_of0 = [&](int s) -> long { return (long)(s / sdiv) * so + (long)(s % sdiv) * si; };
     const long wg_row0 = row_of0(min(s0, nseq - 1));
@@ -501,7 +500,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g)      // exponent clamped like k_intra_xp's (no inf * 0)
-            eb[m][g] = __builtin_amdgcn_exp2f(fminf(fmaxf(b_sum[dir * 256 + g * 64 + unit0 + 4 * m], -100.0f), 100.0f));
+            eb[m][g] = __builtin_amdgcn_exp2f(fminf(fmaxf(b_sum[dir * 256 + g * 64 + unit0 + m], -100.0f), 100.0f));
 
     const int a_frag = l15 * XP_AP + g4 * 8;
     const int a_cell = l15 * XP_AP + C + unit0;
@@ -567,7 +566,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
         const int s = min(s0 + l15, nseq - 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            creg[m] = c0 ? XP_K2 * c0[(long)s * H + unit0 + 4 * m] : 0.0f;
+            creg[m] = c0 ? XP_K2 * c0[(long)s * H + unit0 + m] : 0.0f;
             hreg[m] = 0.0f;
         }
     }
@@ -683,13 +682,16 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
         };
         auto cG = [&](auto m_) { constexpr int m = decltype(m_)::value; tc[m] = 1.0f + __builtin_amdgcn_exp2f(creg[m]); };
         auto cH = [&](auto m_) { constexpr int m = decltype(m_)::value; tc[m] = __builtin_amdgcn_rcpf(tc[m]); };
+        _Float16 th2[2], tl2[2];
         auto cI = [&](auto m_) {
             constexpr int m = decltype(m_)::value;
             hreg[m] = acc[m][3] * __builtin_fmaf(2.0f, tc[m], -1.0f);
-            _Float16 th, tl;
-            split_hl(hreg[m], th, tl);
-            ahi[nxt * NS * XP_AP + a_cell + 4 * m] = th;
-            alo[nxt * NS * XP_AP + a_cell + 4 * m] = tl;
+            split_hl(hreg[m], th2[m], tl2[m]);
+            if constexpr (m == 1) {                // units unit0, unit0 + 1: one packed store per half
+                typedef _Float16 xp_f16x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<xp_f16x2*>(&ahi[nxt * NS * XP_AP + a_cell]) = xp_f16x2{th2[0], th2[1]};
+                *reinterpret_cast<xp_f16x2*>(&alo[nxt * NS * XP_AP + a_cell]) = xp_f16x2{tl2[0], tl2[1]};
+            }
         };
         using M0 = std::integral_constant<int, 0>;
         using M1 = std::integral_constant<int, 1>;
@@ -766,7 +768,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     }
     if (hN) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) hf[l15 * XP_LSP + unit0 + 4 * m] = hreg[m];
+        for (int m = 0; m < 2; ++m) hf[l15 * XP_LSP + unit0 + m] = hreg[m];
     }
     __syncthreads();
     if (lin_wave) {
@@ -778,7 +780,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     }
     if (cN && s0 + l15 < nseq) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + 4 * m] = creg[m] * (1.0f / XP_K2);
+        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + m] = creg[m] * (1.0f / XP_K2);
     }
 }
 

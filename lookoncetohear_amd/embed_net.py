@@ -135,7 +135,12 @@ class EmbedTFGridNet(nn.Module):
                         e0.record()
                         lib_.call(name, *args)
                         e1.record()
-                        prof.append((name + ("" if name != "lh_emb_axis" else (".inter" if args[12] else ".intra")), e0, e1))
+                        tag = name
+                        if name == "lh_emb_axis":
+                            tag = name + (".inter" if args[12] else ".intra")
+                        elif name == "lh_emb_axis_fused":
+                            tag = "lh_emb_axis" + (".inter" if args[10] else ".intra")
+                        prof.append((tag, e0, e1))
             za, zb, zc = e(B, T, F_, C_), e(B, T, F_, C_), e(B, T, F_, C_)
             inv_std = e(B)
             tiles = B * ((T + 13) // 14)
@@ -156,10 +161,13 @@ class EmbedTFGridNet(nn.Module):
             for i in range(self.n_layers):
                 bp = pk["blocks"][i]
                 if self.fused_axis:
+                    # the normalised, split input of an axis call is emitted by whichever kernel wrote that activation: the
+                    # intra call's transposed conv for the inter call, the attention block's projection for the next
+                    # block's intra call; only block 0's intra input (the front end's output) needs its own launch
                     lib.call("lh_emb_axis_fused", P(za), P(bp["intra_wrec"]), P(bp["intra_brec"]), P(bp["intra_wct"]),
-                             P(bp["intra_bct"]), P(xsp), P(hbuf), P(zb), B, T, 0, st)
+                             P(bp["intra_bct"]), P(xsp), P(hbuf), P(zb), B, T, 0, int(i > 0), 1, st)
                     lib.call("lh_emb_axis_fused", P(zb), P(bp["inter_wrec"]), P(bp["inter_brec"]), P(bp["inter_wct"]),
-                             P(bp["inter_bct"]), P(xsp), P(hbuf), P(zc), B, T, 1, st)
+                             P(bp["inter_bct"]), P(xsp), P(hbuf), P(zc), B, T, 1, 1, 0, st)
                 else:
                     lib.call("lh_emb_axis", P(za), P(bp["intra_wih"]), P(bp["intra_bih"]), P(bp["intra_whh"]), P(bp["intra_wct"]),
                              P(bp["intra_bct"]), P(xsp), P(gx), P(hbuf), P(zb), B, T, 0, st)
@@ -170,7 +178,7 @@ class EmbedTFGridNet(nn.Module):
                 lib.call("lh_emb_attn_block", P(zc), P(bp["wqkv"]), P(bp["bqkv"]), P(bp["slopes"]), P(bp["lnq_w"]),
                          P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(bp["wproj"]),
                          P(bp["bproj"]), P(bp["slope_p"]), P(bp["lnp_w"]), P(bp["lnp_b"]), P(qb), P(kb), P(vb), P(vtb), P(scb), P(pb), P(zb), P(za),
-                         B, T, st)
+                         P(xsp) if (self.fused_axis and i + 1 < self.n_layers) else None, B, T, st)
                 if taps is not None:
                     taps[f"blocks.{i}.O"], taps[f"blocks.{i}.out"] = zb.clone(), za.clone()
             emb = e(B, self.embed_dim)

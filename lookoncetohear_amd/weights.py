@@ -113,8 +113,9 @@ def pack_lstm_f16x3_w8(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
     """Image of the eight-wave fused kernel (lh_lstm.hip k_lstm_lin8p), where the weights are the MFMA **A** operand of a
     transposed gate GEMM: [8 waves, 2 tiles, 4 ksteps, 64 lanes, 2 (hi|lo), 8] fp16, lo unscaled, rows pre-scaled by
     `gate_prescale`.  Lane l of (wave v, tile m, k-step ks) holds row  gate*64 + unit  of [W_ih | W_hh] with
-    gate = (l & 15) & 3, unit = 8v + 4m + ((l & 15) >> 2), at k = ks*32 + (l >> 4)*8 + j: the accumulator tile is then
-    [16 rows = (unit, gate)] x [16 sequences] and a lane's four registers are the four gates of one unit."""
+    gate = (l & 15) & 3, unit = 8v + 2 ((l & 15) >> 2) + m, at k = ks*32 + (l >> 4)*8 + j: the accumulator tile is then
+    [16 rows = (unit, gate)] x [16 sequences], a lane's four registers are the four gates of one unit, and its two tiles
+    hold ADJACENT units (round 4: h leaves the cell update as one packed 4-byte LDS store per half)."""
     H = w_hh.shape[1]
     assert H == 64 and tuple(w_ih.shape) == (4 * H, 64)
     wcat = torch.cat([w_ih, w_hh], dim=1).double()
@@ -126,7 +127,7 @@ def pack_lstm_f16x3_w8(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
     ks = torch.arange(4, device=dev)[None, None, :, None, None]
     j = torch.arange(8, device=dev)[None, None, None, None, :]
     rho = (lane & 15)[None, None, None, :, None]
-    row = (rho & 3) * H + wave * 8 + tile * 4 + (rho >> 2)
+    row = (rho & 3) * H + wave * 8 + 2 * (rho >> 2) + tile
     k = ks * 32 + (lane >> 4)[None, None, None, :, None] * 8 + j
     hi, lo = split_f16_unscaled(wcat[row, k])
     return torch.stack([hi, lo], dim=4).contiguous()             # [8,2,4,64,2,8]
