@@ -40,10 +40,12 @@ enum {
  * result is finite in fp32 is computed to the same ~22 bits relative to the row maximum — the reference's behaviour
  * (plain fp32, tfgridnet_causal.py:188-283).  What remains is a GUARD for non-finite data: lh_deconv_istft stores 0 (not
  * NaN / inf) for a non-finite output sample and raises a CALLER-OWNED flag:
- *   range_flag       device memory, two 32-bit words, zero-initialised by the caller: [0] = sticky word raised by
- *                    lh_deconv_istft (NULL = no reporting), [1] = the value the last fetch took out of [0].  Each Net /
- *                    Streamer / host thread owns its own, so concurrent forwards on one device cannot consume or clear
- *                    one another's flag (ABI <= 11 kept one word per device).
+ *   range_flag       two 32-bit words of DEVICE-ACCESSIBLE memory (device memory, or pinned host memory the caller reads
+ *                    directly — the streaming host does that and needs no polling launch at all), zero-initialised by the
+ *                    caller: [0] = sticky word lh_deconv_istft sets to 1 with a system-scope store (NULL = no reporting),
+ *                    [1] = the value the last fetch took out of [0].  Each Net / Streamer / host thread owns its own, so
+ *                    concurrent forwards on one device cannot consume or clear one another's flag (ABI <= 11 kept one
+ *                    word per device).
  *   lh_range_status: [1] = atomicExch([0], 0) on `stream`, copies [1] to the host, WAITS for the stream; LH_OK, or
  *                    LH_ERR_RANGE when it was set.  The one entry point that synchronises: call it once per forward.
  *   lh_range_flag_copy: the same exchange followed by an asynchronous copy of [1] to `host_pinned` (4 bytes of pinned host

@@ -63,13 +63,13 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     // the synthesis filterbank tiles 2w, 2w+1 (of 12; 112 registers) are fetched from L2 once per tile, right before
     // they are used — the registers hold the frame prefetch ring while the frames stream
     __shared__ __attribute__((aligned(16))) _Float16 wds[3 * 2 * 64 * 16];
-    // Range-safe splits (pow2_scale, lh_common.h).  The frames are rows of the un-normalised residual stream: each row is
-    // scaled by its own power of two, `rinv[q][row]` undoes it on the partial products.  The spectra are split a second
+    // Range-safe splits (pow2_scale, lh_common.h).  The frames are rows of the un-normalised residual stream: the rows a wave
+    // stages share one power of two per frame (stage_frame), `rinv[q][row]` undoes it on the partial products.  The spectra are split a second
     // time (synthesis A image): frame td is scaled by a power of two taken from a BOUND of its magnitude,
     //     |D[td]| <= max|b| + 3 W1 (M[td] + M[td-1] + M[td-2]),   M[fr] = max |Y[fr]|,  W1 = max_col sum_c |Wd[col][c]|
     // (data-independent of the products, so no extra barrier); `sinv[jd]` undoes it on the synthesis accumulators.
     __shared__ __attribute__((aligned(16))) float rinv[2][FR_RP];
-    __shared__ float wmax[2][32];                     // per 16-lane-group maxima (8 waves x 4) of the two frames being staged
+    __shared__ float wmax[2][BE_NT / 64];             // per-wave maxima of the two frames being staged
     __shared__ float fmaxr[4];                        // M[fr] ring, slot (fr + 4) & 3 like the partial products
     __shared__ __attribute__((aligned(16))) float sinv[BE_NJ];
     __shared__ float w1s[48];
@@ -158,18 +158,25 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
         __syncthreads();
         BE_STAMP(0);
 
-        // one float4 of a frame row (element e: row e >> 4, channels 4 (e & 15) ..) -> A image, scaled by the row's power of
-        // two (the 16 lanes of a row reduce its maximum with DPP; whole rows are in or out of range together); returns the
-        // running maximum of this thread's rows
-        auto stage_row = [&](_Float16* ih, _Float16* il, float* riv, int e, const float4& v, float run) -> float {
-            const float m = group16_max(absmax4(v));
+        // the BE_NLD float4 of a frame this thread stages (element e: row e >> 4, channels 4 (e & 15) ..) -> A image, scaled by
+        // one power of two per WAVE (the rows a wave stages: 16 lanes each, so every row has one scale; lh_split.h
+        // frame_store_scaled); returns the wave's maximum (wave-uniform)
+        auto stage_frame = [&](_Float16* ih, _Float16* il, float* riv, const float4 (&v)[BE_NLD]) -> float {
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < BE_NLD; ++i) m = fmaxf(m, absmax4(v[i]));
+            m = wave_max_uniform(m);
             float sc, iv;
             pow2_scale<FR_TE>(m, sc, iv);
-            if (e < NF * 16) {
-                store_split4<FR_RP>(ih, il, e >> 4, (e & 15) * 4, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
-                if ((e & 15) == 0) riv[e >> 4] = iv;
+#pragma unroll
+            for (int i = 0; i < BE_NLD; ++i) {
+                const int e = tv + BE_NT * i;
+                if (e < NF * 16) {
+                    store_split4<FR_RP>(ih, il, e >> 4, (e & 15) * 4, make_float4(v[i].x * sc, v[i].y * sc, v[i].z * sc, v[i].w * sc));
+                    if ((e & 15) == 0) riv[e >> 4] = iv;
+                }
             }
-            return fmaxf(run, m);
+            return m;
         };
         // one spectrum value -> row jd of source s's A image
         auto put_sx = [&](int jd, int s, int k, float v) {
@@ -189,7 +196,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             __syncthreads();
             float m = wmax[0][0];
 #pragma unroll
-            for (int w = 1; w < BE_NT / 64; ++w) m = fmaxf(m, wmax[0][w]);      // (entries 0..7 here; the frame staging uses all 32)
+            for (int w = 1; w < BE_NT / 64; ++w) m = fmaxf(m, wmax[0][w]);
             float sc, iv;
             pow2_scale<12>(m, sc, iv);
             if (tid < NSRC * NK) put_sx(0, tid / NK, tid % NK, cv * sc);
@@ -248,35 +255,31 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                 // copy into the transpose buffer, then rows of four channels like any other frame
                 for (int i = tid; i < 2 * C * NF; i += BE_NT) tbuf[i] = dbuf_in[(long)b * 2 * C * NF + i];
                 __syncthreads();
-                float tm[2] = {0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < BE_NLD; ++i) {
-                    const int e = min(tv + BE_NT * i, NF * 16 - 1);
-                    const int f = e >> 4, c0 = (e & 15) * 4;
+                for (int q = 0; q < 2; ++q) {
+                    float4 hv[BE_NLD];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float4 hv = make_float4(tbuf[((c0 + 0) * 2 + q) * NF + f], tbuf[((c0 + 1) * 2 + q) * NF + f],
-                                                      tbuf[((c0 + 2) * 2 + q) * NF + f], tbuf[((c0 + 3) * 2 + q) * NF + f]);
-                        tm[q] = stage_row(ahi + q * FR_A, alo + q * FR_A, rinv[q], tv + BE_NT * i, hv, tm[q]);
+                    for (int i = 0; i < BE_NLD; ++i) {
+                        const int e = min(tv + BE_NT * i, NF * 16 - 1);
+                        const int f = e >> 4, c0 = (e & 15) * 4;
+                        hv[i] = make_float4(tbuf[((c0 + 0) * 2 + q) * NF + f], tbuf[((c0 + 1) * 2 + q) * NF + f],
+                                            tbuf[((c0 + 2) * 2 + q) * NF + f], tbuf[((c0 + 3) * 2 + q) * NF + f]);
                     }
+                    const float wm = stage_frame(ahi + q * FR_A, alo + q * FR_A, rinv[q], hv);
+                    if (lane == 0) wmax[q][wave] = wm;
                 }
-                if (l15 == 0) { wmax[0][wave * 4 + g4] = tm[0]; wmax[1][wave * 4 + g4] = tm[1]; }   // (row maxima are group-uniform)
                 __syncthreads();
                 zero_guards();                        // the buffer ran over guard rows; the products below write rows 1..97 only
             } else {
-                float tm[2] = {0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < BE_NLD; ++i) {
-                    tm[0] = stage_row(ahi, alo, rinv[0], tv + BE_NT * i, stg[u][i], tm[0]);
-                    if (two) tm[1] = stage_row(ahi + FR_A, alo + FR_A, rinv[1], tv + BE_NT * i, stg[u + 1][i], tm[1]);
-                }
-                if (l15 == 0) { wmax[0][wave * 4 + g4] = tm[0]; wmax[1][wave * 4 + g4] = tm[1]; }   // (row maxima are group-uniform)
+                const float wm0 = stage_frame(ahi, alo, rinv[0], stg[u]);
+                const float wm1 = two ? stage_frame(ahi + FR_A, alo + FR_A, rinv[1], stg[u + 1]) : 0.f;
+                if (lane == 0) { wmax[0][wave] = wm0; wmax[1][wave] = wm1; }
             }
             __syncthreads();
             if (wave == 7) {                           // the one wave without a product tile: M[fr], M[fr + 1] for the spectrum
 #pragma unroll                                         // bounds of frames fr .. fr + 3, off the other waves' path
                 for (int q = 0; q < 2; ++q) {
-                    const float m = wave_max(lane < 32 ? wmax[q][lane] : 0.f);
+                    const float m = wave_max(lane < BE_NT / 64 ? wmax[q][lane] : 0.f);
                     if (lane == 0 && (q == 0 || two)) fmaxr[(fr + q + 4) & 3] = m;
                 }
             }
@@ -434,7 +437,9 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             wave_out[((long)b * NSRC + s) * L + (long)(t0 + jt) * HOP + n] = nf ? 0.f : v;
             bad |= nf;
         }
-        if (bad && range_flag) atomicOr(range_flag, 1u);      // sticky until lh_range_status / lh_range_flag_copy fetch it
+        // sticky until lh_range_status / lh_range_flag_copy fetch it.  A plain store (every writer writes 1), system scope: the
+        // word may live in device memory or in pinned host memory the caller reads directly (Streamer: no polling launches)
+        if (bad && range_flag) __hip_atomic_store(range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
         // frs lived in the hi A images: their pad rows (97..111 feed dropped outputs) must hold finite numbers again —
         // only those: the 97 real rows are rewritten by the staging of the next frames

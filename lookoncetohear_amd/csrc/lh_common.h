@@ -129,6 +129,15 @@ __device__ __forceinline__ float group16_max(float v) {
     u = row_ror_umax<2>(u);
     return __uint_as_float(row_ror_umax<1>(u));
 }
+// wave-uniform max of non-negative floats: 4 folded DPP steps, then the four row leaders through v_readlane / s_max (the
+// result lives in an SGPR: everything derived from it — pow2_scale — runs on the scalar unit)
+__device__ __forceinline__ float wave_max_uniform(float v) {
+    const unsigned u = __float_as_uint(group16_max(v));
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)u, 0), b = (unsigned)__builtin_amdgcn_readlane((int)u, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)u, 32), d = (unsigned)__builtin_amdgcn_readlane((int)u, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return __uint_as_float(ab > cd ? ab : cd);
+}
 __device__ __forceinline__ float wave_max(float v) {
     v = group16_max(v);
     v = fmaxf(v, __shfl_xor(v, 16));

@@ -101,19 +101,23 @@ __device__ __forceinline__ void frame_store(_Float16* ahi, _Float16* alo, int ti
         if (e < NF * 16) store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, stg[i]);
     }
 }
-// Range-safe variant for frames of the UN-NORMALISED residual stream (k_qkv_proj_ln, k_deconv_istft): every row (one TF
-// unit = the 16 lanes that hold its 64 channels) is multiplied by its own power of two before the split (pow2_scale,
-// lh_common.h); `rinv[row]` receives 1 / scale for the accumulator epilogue (row r of the product = rinv[r] * acc).
-constexpr int FR_TE = 12;                  // row maximum scaled into [2^12, 2^13): 3 bits of headroom below 65504
+// Range-safe variant for frames of the UN-NORMALISED residual stream (k_qkv_proj_ln): the rows a WAVE stages (rows 4w .. 4w+3
+// of every group of 16: each row = 16 lanes of one wave) are multiplied by one power of two taken from their common maximum
+// before the split (pow2_scale, lh_common.h); `rinv[row]` receives 1 / scale for the accumulator epilogue (row r of the
+// product = rinv[r] * acc).  One wave-level maximum per frame (14 max3 + 4 DPP + 4 readlane, the scale itself on the scalar
+// unit) instead of one 16-lane reduction per row: the first form of this function cost the VALU-bound QKV kernel +9 %.
+// Precision: 22 bits relative to the largest of the wave's 28 rows, with 2^-37 of it as absolute floor (TE = 12).
+constexpr int FR_TE = 12;                  // group maximum scaled into [2^12, 2^13): 3 bits of headroom below 65504
 __device__ __forceinline__ void frame_store_scaled(_Float16* ahi, _Float16* alo, float* rinv, int tid,
                                                    const float4 (&stg)[FR_NLD]) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < FR_NLD; ++i) m = fmaxf(m, absmax4(stg[i]));      // (slots past the frame hold clamped duplicates)
+    float s, inv;
+    pow2_scale<FR_TE>(wave_max_uniform(m), s, inv);
 #pragma unroll
     for (int i = 0; i < FR_NLD; ++i) {
         const int e = tid + 256 * i;
-        // all 16 lanes of a row take the same branch (e >> 4 is the row): the DPP reduction sees whole rows
-        const float m = group16_max(absmax4(stg[i]));
-        float s, inv;
-        pow2_scale<FR_TE>(m, s, inv);
         if (e < NF * 16) {
             store_split4<FR_RP>(ahi, alo, e >> 4, (e & 15) * 4, make_float4(stg[i].x * s, stg[i].y * s, stg[i].z * s, stg[i].w * s));
             if ((e & 15) == 0) rinv[e >> 4] = inv;

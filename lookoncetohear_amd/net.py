@@ -570,15 +570,15 @@ class Streamer:
         self.pos = z(1, dtype=torch.int32)
         self.gain = z(B, F_, C_)
         self.gain_raw = z(B, F_ * C_)
-        # range guard: THIS streamer's own two-word device flag (never shared with the Net's offline forwards or another
-        # streamer).  Every RANGE_POLL-th chunk an exchange kernel + asynchronous 4-byte copy into pinned host memory
-        # follows the chunk's launches (outside the captured graph: a copy node per chunk cost 26 us of a 0.30 ms chunk),
-        # and the word is looked at when later chunks arrive — so a non-finite chunk (output: zeros) raises within
-        # RANGE_POLL + 1 chunks
-        self.range_flag = z(2, dtype=torch.int32)
-        self.range_word = torch.zeros(1, dtype=torch.int32)
+        # range guard: THIS streamer's own two-word flag (never shared with the Net's offline forwards or another streamer);
+        # a non-finite chunk (output: zeros) raises at the first `step` after that chunk has finished on the device.
+        # On the GPU the flag lives in PINNED HOST memory (device-accessible under unified addressing): the back end stores
+        # to it directly in the rare chunk that needs it and `step` just reads the word — no exchange kernel, no copy, no
+        # extra launches in the chunk loop (round 3 polled with a kernel + copy every 64th chunk: +0.15 ms on that chunk,
+        # which was the p99 of the latency distribution).
+        self.range_flag = torch.zeros(2, dtype=torch.int32)
         if dev.type == "cuda":
-            self.range_word = self.range_word.pin_memory()
+            self.range_flag = self.range_flag.pin_memory()
         self.parity = 0
         self.graphs = None
         self.graph = None
@@ -608,8 +608,6 @@ class Streamer:
             self.graph = self.graphs[0]
             self.reset()
 
-    RANGE_POLL = 8           # chunks between polls of the range flag (64 ms of audio)
-
     def _version_stamp(self) -> int:
         if self.net._blob is not None:
             return 0
@@ -633,7 +631,6 @@ class Streamer:
             vx.zero_()
         self.pos.zero_()
         self.range_flag.zero_()
-        self.range_word.zero_()
         self.parity = 0
 
     def set_embedding(self, embed: torch.Tensor):
@@ -651,8 +648,8 @@ class Streamer:
         if cur is not self._pk:
             raise RuntimeError("the Net's parameters changed after this Streamer was built (its HIP graphs hold pointers "
                                "into the old packed weights): create a new streamer with net.make_streamer(...)")
-        if int(self.range_word[0]) != 0:
-            self.range_word.zero_()              # (the device word was cleared by the exchange that fetched it)
+        if net.range_check and int(self.range_flag[0]) != 0:     # host read of the pinned word: free
+            self.range_flag.zero_()
             raise RuntimeError("LH_ERR_RANGE: an earlier chunk produced non-finite samples, emitted as zeros (inf / NaN in "
                                "the input or in the carried state); reset() the streamer")
         # ... and a parameter updated IN PLACE (optimizer step, load_state_dict) without any other `Net` call in between
@@ -668,9 +665,5 @@ class Streamer:
                 self.graphs[self.parity].replay()
             else:
                 self._body(self.parity)
-            if net.range_check and (self._n_steps % self.RANGE_POLL) == 0:
-                st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-                with _device_of(self.chunk):
-                    net._lib(self.chunk).call("lh_range_flag_copy", self.range_flag.data_ptr(), self.range_word.data_ptr(), st)
         self.parity ^= 1
         return self.out

@@ -458,6 +458,8 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, in
 #define __builtin_amdgcn_s_getreg(x) (0u)
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
 #define __builtin_amdgcn_readfirstlane(x) (x)
+// v_readlane_b32: every lane of the wave gets lane `l`'s value (all lanes must be active, as on the hardware uses here)
+#define __builtin_amdgcn_readlane(x, l) hipemu::shfl_any((int)(x), (hipemu::lane_id() & ~63) | (l))
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
@@ -475,5 +477,7 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 static inline unsigned atomicExch(unsigned* p, unsigned v) { unsigned o = *p; *p = v; return o; }
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

@@ -333,10 +333,9 @@ def test_range_guard_is_per_caller_and_emits_silence(emu_net, oracle_cfg_sd):
         emu_net(bad, d["embedding_gt"])
     assert torch.equal(emu_net(d["mixture"], d["embedding_gt"]), yo)
     st = emu_net.make_streamer(1, "cpu", use_graph=False)
-    st.RANGE_POLL = 2
     st.set_embedding(d["embedding_gt"][:, 0])
     st.step(d["mixture"][:, :, :192])
-    out = st.step(bad[:, :, :192]).clone()                 # non-finite chunk; polled after it, noticed at the next one
+    out = st.step(bad[:, :, :192]).clone()                 # non-finite chunk: the next step sees its flag word
     assert torch.isfinite(out).all()
     assert emu_net.range_status("cpu") is False            # the streamer's flag is not the Net's
     with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):

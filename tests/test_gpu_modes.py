@@ -208,7 +208,15 @@ def test_range_flag_belongs_to_its_caller(oracle_cfg_sd):
     st.set_embedding(e[:1, 0])
     for i in range(10):
         st.step(x[:1, :, i * 128:i * 128 + 192])
-    assert a.range_status(DEV) is False and not int(st.range_word[0])
+    torch.cuda.synchronize()
+    assert a.range_status(DEV) is False and not int(st.range_flag[0])
+    badc = x[:1, :, :192].clone()
+    badc[0, 0, 10] = float("nan")
+    st.step(badc)                                          # the streamer's own pinned-host word: raised by the kernel itself
+    torch.cuda.synchronize()
+    assert int(st.range_flag[0]) == 1 and a.range_status(DEV) is False
+    with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
+        st.step(x[:1, :, :192])
 
 
 def test_stage_taps_are_bit_reproducible(nets):
