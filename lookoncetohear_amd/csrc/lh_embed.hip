@@ -586,7 +586,7 @@ constexpr int ER_NFRAG = 2 * (EKS * 2 + 2) * 2;   // per wave: 2 tiles x (4 slot
 template <bool INTER>
 __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict__ xs, const _Float16* __restrict__ w_pk,
                                                       const float* __restrict__ bias, _Float16* __restrict__ hs, int nseq,
-                                                      int P, int T, long rows_x) {
+                                                      int P, int T, long rows_x, int prio) {
     __shared__ __attribute__((aligned(16))) _Float16 ring[ER_RING * ER_POS];
     __shared__ __attribute__((aligned(16))) _Float16 himg[2 * ER_POS];
     __shared__ __attribute__((aligned(16))) float bsm[256];
@@ -749,6 +749,14 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
                 *reinterpret_cast<f16x2*>(hrow) = f16x2{sh_[0], sh_[1]};
                 *reinterpret_cast<f16x2*>(hrow + 64) = f16x2{sl_[0], sl_[1]};
             }
+            if constexpr (k == 30) {                     // row-wise roles, inside the MFMA stream instead of behind it
+                if (loader) {                            // position it + 6 (loaded two steps ago) -> ring; fetch it + 8
+                    put_pos(it + 6, stg);
+                    stg = load_pos(it + 8);
+                } else if (it > 0) {
+                    flush_h(it - 1, cur);
+                }
+            }
         };
         auto x_group = [&](auto g_, auto zip_) {          // 6 MFMAs of group g; with zip: cell slice + fence after each
             constexpr int g = decltype(g_)::value, k4 = g >> 1, ks = g & 1, b = g & 1;
@@ -768,6 +776,9 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
         };
         x_group(std::integral_constant<int, 0>{}, std::false_type{});
         __builtin_amdgcn_sched_barrier(0);
+        // issue priority for the MFMAs on the chain (lh_set_tuning key 16): the SIMD's other wave is in its off-chain groups
+        // half of the time, and the arbiter otherwise lets those in first (k_inter_xp: -22 % from the same switch)
+        if (prio) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -776,18 +787,13 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
                 ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whh[j][ks], hl[ks], ac[j], 0, 0, 0);
                 ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whl[j][ks], hh[ks], ac[j], 0, 0, 0);
             }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         xp_for<7>([&](auto g_) { x_group(std::integral_constant<int, decltype(g_)::value + 1>{}, std::true_type{}); });
         if (more) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 gxn[j] = f32x4{xm[j][0] + xc[j][0], xm[j][1] + xc[j][1], xm[j][2] + xc[j][2], xm[j][3] + xc[j][3]};
-        }
-        if (loader) {                                    // position it + 6 (loaded two steps ago) -> ring; fetch it + 8
-            put_pos(it + 6, stg);
-            stg = load_pos(it + 8);
-        } else if (it > 0) {
-            flush_h(it - 1, cur);
         }
         __syncthreads();
     };
@@ -1510,6 +1516,15 @@ extern "C" int lh_emb_axis(const float* x, const void* wih_pk, const float* bih,
     return check_launch();
 }
 
+namespace lh {
+static int g_rec_prio = 0;              // lh_set_tuning key 16: issue priority for k_emb_rec's on-chain MFMAs (0 = off)
+int emb_set(int key, int value) {
+    if (key != 16 || value < 0 || value > 1) return LH_ERR_ARG;
+    g_rec_prio = value;
+    return LH_OK;
+}
+}  // namespace lh
+
 // One axis path, round-4 form (see k_emb_rec): LayerNorm + split (k_emb_lnsplit) -> k_emb_rec (input GEMM + recurrence,
 // both directions in one launch) -> k_emb_convt2 (+ residual).  No gate pre-activation buffer.
 //   wrec_pk fp16 [2 dirs][8 waves][40 fragments][64 lanes][8] (embed_net.py pack_rec); brec [2][256] in (unit, gate) order,
@@ -1536,12 +1551,12 @@ extern "C" int lh_emb_axis_fused(const float* x, const void* wrec_pk, const floa
     _Float16* xs_next = emit_split ? (_Float16*)xsplit : nullptr;
     if (inter) {
         hipLaunchKernelGGL((k_emb_rec<true>), dim3((nseq + 15) / 16, 2), dim3(ER_NT), 0, st, (const _Float16*)xsplit,
-                           (const _Float16*)wrec_pk, brec, (_Float16*)hsplit, nseq, P, T, rows);
+                           (const _Float16*)wrec_pk, brec, (_Float16*)hsplit, nseq, P, T, rows, g_rec_prio);
         hipLaunchKernelGGL((k_emb_convt2<true>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
                            (const _Float16*)wct_pk, bct, x, out, xs_next, rows, nseq, P, T);
     } else {
         hipLaunchKernelGGL((k_emb_rec<false>), dim3((nseq + 15) / 16, 2), dim3(ER_NT), 0, st, (const _Float16*)xsplit,
-                           (const _Float16*)wrec_pk, brec, (_Float16*)hsplit, nseq, P, T, rows);
+                           (const _Float16*)wrec_pk, brec, (_Float16*)hsplit, nseq, P, T, rows, g_rec_prio);
         hipLaunchKernelGGL((k_emb_convt2<false>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
                            (const _Float16*)wct_pk, bct, x, out, xs_next, rows, nseq, P, T);
     }

@@ -1029,6 +1029,7 @@ static int cu_count() {
     }
     return n;
 }
+int emb_set(int key, int value);        // lh_embed.hip
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // [0] intra MT (0 = auto), [1] inter MT (0 = auto), [3] 0 = no issue-priority de-phasing
 }
 namespace lh { int attn_set_mq(int v); }      // lh_attn.hip
@@ -1050,6 +1051,7 @@ extern "C" int lh_set_tuning(int key, int value) {
     if (key == 4) return lh::attn_set_mq(value);
     if (key == 6) return lh::backend_set_runs(value);
     if (key >= 7 && key < 16) return lh::xp_set(key, value);      // lh_recur.hip switches
+    if (key == 16) return lh::emb_set(key, value);                // lh_embed.hip: k_emb_rec issue priority
     if (key < 0 || key >= 8) return LH_ERR_ARG;
     lh::g_tune[key] = value;
     if (key == 3) lh::g_dephase = value;

@@ -406,8 +406,8 @@ def test_packed_blob_is_a_sufficient_weight_source(emu_net, tmp_path):
 
 def test_streamer_refuses_stale_weights(emu_net):
     """A `Streamer` holds pointers into the packed weights it was built with: after a re-pack (any `Net` call following a
-    parameter change) the next chunk raises; after an in-place update with no other call in between, the version stamp
-    checked every 64th chunk does."""
+    parameter change) the next chunk raises; after an in-place update with no other call in between, the rolling check of
+    the tensors' version counters (three per chunk) does."""
     d = synth.batch([4], 128 * 2 + 64)
     st = emu_net.make_streamer(1, "cpu", use_graph=False)
     st.set_embedding(d["embedding_gt"][:, 0])
@@ -417,7 +417,7 @@ def test_streamer_refuses_stale_weights(emu_net):
     try:
         with torch.no_grad():
             p.add_(0.0)                                   # in place: version counter moves, `_packed` does not
-        st._n_steps = 63
+        st._vpos = 0                                      # the first parameter is among the next three checked
         with pytest.raises(RuntimeError, match="modified in place"):
             st.step(d["mixture"][:, :, :192])
         emu_net(d["mixture"][:, :, :320], d["embedding_gt"])      # any Net call re-packs
