@@ -262,10 +262,11 @@ int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_bu
  *   x [B][2][n_samples]; inv_std [B] (out); wfb_pk fp32 MFMA image [9][32][64] of the windowed DFT rows [128 x 130];
  *   wconv_pk [4][9][64] of conv.0.weight as [36 taps] x [64]; bconv, gn_w, gn_b [64];
  *   gn_part fp64 scratch [B * ceil(T/14)][2]; z [B][T][65][64] out, T = n_samples/64 + 1
+ *   xsplit_next  NULL, or 2*B*T*65*64 fp16: z channel-normalised and split, for lh_emb_axis_fused(have_xsplit = 1)
  */
 int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_pk, const float* wconv_pk, const float* bconv,
-                    const float* gn_w, const float* gn_b, double* gn_part, float* z, int B, int T, int n_samples,
-                    lh_stream_t stream);
+                    const float* gn_w, const float* gn_b, double* gn_part, float* z, void* xsplit_next, int B, int T,
+                    int n_samples, lh_stream_t stream);
 
 /* One axis path of an espnet2 GridNetBlock of the embedder (intra: inter = 0, sequences = frames, scan over the 65
  * bins; inter = 1: sequences = bins, scan over time): LayerNorm(C) -> unfold(4) -> BiLSTM(256 -> 64) ->

@@ -35,7 +35,7 @@ SIGNATURES = {
     "lh_ring_advance": [_P, _I, _P],
     "lh_proj_ln_res": [_P] * 9 + [_I, _I, _P],
     "lh_deconv_istft": [_P] * 10 + [_I, _I, _P],
-    "lh_emb_frontend": [_P] * 9 + [_I, _I, _I, _P],
+    "lh_emb_frontend": [_P] * 10 + [_I, _I, _I, _P],
     "lh_emb_axis": [_P] * 10 + [_I, _I, _I, _P],
     "lh_emb_axis_fused": [_P] * 8 + [_I, _I, _I, _I, _I, _P],
     "lh_emb_attn_block": [_P] * 24 + [_I, _I, _P],

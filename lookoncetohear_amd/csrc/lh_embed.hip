@@ -197,8 +197,29 @@ __global__ void __launch_bounds__(256, 1) k_emb_stft_conv(const float* __restric
 }
 
 // GroupNorm(1, 64) over (C, T, F) of one utterance, affine per channel; in place.  grid (chunks, B)
+// one float4 (channels 4q .. 4q+3) of a 64-channel row held by 16 consecutive lanes; every lane of the group must call it
+__device__ __forceinline__ void ln_split_store(float4 u, _Float16* __restrict__ xh, _Float16* __restrict__ xl, long off, bool valid) {
+    const float mean = group16_sum(u.x + u.y + u.z + u.w) * (1.0f / C);
+    u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
+    const float var = group16_sum(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.0f / C);
+    const float rstd = rsqrtf(var + LN_EPS);
+    const float v[4] = {u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd};
+    f16x4 h4, l4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        _Float16 h, l;
+        split_hl(v[i], h, l);
+        h4[i] = h;
+        l4[i] = l;
+    }
+    if (valid) {
+        *reinterpret_cast<f16x4*>(&xh[off]) = h4;
+        *reinterpret_cast<f16x4*>(&xl[off]) = l4;
+    }
+}
 __global__ void __launch_bounds__(256) k_emb_gn_apply(float* __restrict__ z, const double* __restrict__ gn_part,
-                                                      const float* __restrict__ gw, const float* __restrict__ gb, int T) {
+                                                      const float* __restrict__ gw, const float* __restrict__ gb,
+                                                      _Float16* __restrict__ xs_next, long rows_x, int T) {
     __shared__ float stat[2];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int tiles_per_b = (T + EM_TT - 1) / EM_TT;
@@ -221,6 +242,8 @@ __global__ void __launch_bounds__(256) k_emb_gn_apply(float* __restrict__ z, con
         v.x = (v.x - mean) * rstd * w4.x + b4.x; v.y = (v.y - mean) * rstd * w4.y + b4.y;
         v.z = (v.z - mean) * rstd * w4.z + b4.z; v.w = (v.w - mean) * rstd * w4.w + b4.w;
         *reinterpret_cast<float4*>(&zb[i * 4]) = v;
+        // block 0's intra axis call reads these rows channel-normalised and split (16 lanes = one row: i & 15 = tid & 15)
+        if (xs_next) ln_split_store(v, xs_next, xs_next + rows_x * C, (long)b * T * EF * C + i * 4, true);
     }
 }
 
@@ -280,26 +303,6 @@ __device__ __forceinline__ long pos_row(int s, int pk, int T) {
 
 // channel LayerNorm (no affine: folded into the packed input weights) + fp16 hi/lo split of every position row, once
 // per axis call: xs = [hi image rows*64 halves | lo image rows*64 halves]; 16 lanes per 256-byte row
-// one float4 (channels 4q .. 4q+3) of a 64-channel row held by 16 consecutive lanes; every lane of the group must call it
-__device__ __forceinline__ void ln_split_store(float4 u, _Float16* __restrict__ xh, _Float16* __restrict__ xl, long off, bool valid) {
-    const float mean = group16_sum(u.x + u.y + u.z + u.w) * (1.0f / C);
-    u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
-    const float var = group16_sum(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.0f / C);
-    const float rstd = rsqrtf(var + LN_EPS);
-    const float v[4] = {u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd};
-    f16x4 h4, l4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        _Float16 h, l;
-        split_hl(v[i], h, l);
-        h4[i] = h;
-        l4[i] = l;
-    }
-    if (valid) {
-        *reinterpret_cast<f16x4*>(&xh[off]) = h4;
-        *reinterpret_cast<f16x4*>(&xl[off]) = l4;
-    }
-}
 __global__ void __launch_bounds__(256) k_emb_lnsplit(const float* __restrict__ x, _Float16* __restrict__ xs, long rows) {
     const int tid = threadIdx.x, q = tid & 15;
     _Float16* xh = xs;
@@ -1205,6 +1208,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
         for (int jn = 0; jn < 4; ++jn) { am[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     fetch(0);
     const int nk = K / 32;
+    const int jn_live = min(4, max(0, (N - (n0 + wn * 64) + 15) / 16));      // 16-column sub-tiles of this wave with any column < N
 #pragma unroll 1
     for (int ks = 0; ks < nk; ++ks) {
         _Float16* buf = &sm[ks & 1][0][0];
@@ -1229,9 +1233,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
             const f16x8 al = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
 #pragma unroll
             for (int jn = 0; jn < 4; ++jn) {
-                am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
-                ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], ac[i][jn], 0, 0, 0);
-                ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], ac[i][jn], 0, 0, 0);
+                if (jn < jn_live) {      // (wave-uniform) N = 1040 leaves 112 of the last tile's 128 columns empty: no MFMAs for those
+                    am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
+                    ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], ac[i][jn], 0, 0, 0);
+                    ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], ac[i][jn], 0, 0, 0);
+                }
             }
         }
     }
@@ -1465,7 +1471,7 @@ __global__ void __launch_bounds__(256) k_emb_head_mean(const float* __restrict__
 
 extern "C" int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_pk, const float* wconv_pk,
                                const float* bconv, const float* gn_w, const float* gn_b, double* gn_part, float* z,
-                               int B, int T, int n_samples, lh_stream_t stream) {
+                               void* xsplit_next, int B, int T, int n_samples, lh_stream_t stream) {
     using namespace lh;
     if (!x || !inv_std || !wfb_pk || !wconv_pk || !bconv || !gn_w || !gn_b || !gn_part || !z || B <= 0 || T <= 0)
         return LH_ERR_ARG;
@@ -1475,7 +1481,8 @@ extern "C" int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_
     const int tiles = B * ((T + EM_TT - 1) / EM_TT);
     hipLaunchKernelGGL(k_emb_stft_conv, dim3(tiles < 256 ? tiles : 256), dim3(256), 0, st, x, inv_std, wfb_pk, wconv_pk,
                        bconv, z, gn_part, B, T, n_samples);
-    hipLaunchKernelGGL(k_emb_gn_apply, dim3(64, B), dim3(256), 0, st, z, gn_part, gn_w, gn_b, T);
+    hipLaunchKernelGGL(k_emb_gn_apply, dim3(64, B), dim3(256), 0, st, z, gn_part, gn_w, gn_b, (_Float16*)xsplit_next,
+                       (long)B * T * EF, T);
     return check_launch();
 }
 

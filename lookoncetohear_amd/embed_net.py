@@ -145,14 +145,14 @@ class EmbedTFGridNet(nn.Module):
             inv_std = e(B)
             tiles = B * ((T + 13) // 14)
             gn_part = torch.empty(tiles * 2, device=dev, dtype=torch.float64)
+            xsp = e(B, T, F_, C_)              # fp16 hi | lo images of the normalised axis input (same bytes as fp32)
             lib.call("lh_emb_frontend", P(x), P(inv_std), P(pk["wfb"]), P(pk["conv_w"]), P(pk["conv_b"]), P(pk["gn_w"]),
-                     P(pk["gn_b"]), P(gn_part), P(za), B, T, N, st)
+                     P(pk["gn_b"]), P(gn_part), P(za), P(xsp) if self.fused_axis else None, B, T, N, st)
             if taps is not None:
                 taps["z0"] = za.clone()
             P_i, P_e = F_ - 3, T - 3
             gx = e(max(B * T * P_i, B * F_ * P_e) * 512) if not self.fused_axis else None
             hbuf = e(max(B * T * P_i, B * F_ * P_e) * 128)
-            xsp = e(B, T, F_, C_)              # fp16 hi | lo images of the normalised axis input (same bytes as fp32)
             nb, Tp = self.n_head * B, (T + 63) // 64 * 64
             h16 = lambda n: torch.empty(n, device=dev, dtype=torch.float16)
             qb, kb = h16(2 * nb * T * 544), h16(2 * nb * T * 544)       # fp16 hi | lo images, rows padded 520 -> 544
@@ -163,9 +163,9 @@ class EmbedTFGridNet(nn.Module):
                 if self.fused_axis:
                     # the normalised, split input of an axis call is emitted by whichever kernel wrote that activation: the
                     # intra call's transposed conv for the inter call, the attention block's projection for the next
-                    # block's intra call; only block 0's intra input (the front end's output) needs its own launch
+                    # block's intra call, the front end's GroupNorm pass for block 0
                     lib.call("lh_emb_axis_fused", P(za), P(bp["intra_wrec"]), P(bp["intra_brec"]), P(bp["intra_wct"]),
-                             P(bp["intra_bct"]), P(xsp), P(hbuf), P(zb), B, T, 0, int(i > 0), 1, st)
+                             P(bp["intra_bct"]), P(xsp), P(hbuf), P(zb), B, T, 0, 1, 1, st)
                     lib.call("lh_emb_axis_fused", P(zb), P(bp["inter_wrec"]), P(bp["inter_brec"]), P(bp["inter_wct"]),
                              P(bp["inter_bct"]), P(xsp), P(hbuf), P(zc), B, T, 1, 1, 0, st)
                 else:
