@@ -246,3 +246,24 @@ def test_embedder_batch_invariance_and_determinism(embedder):
         net_e(torch.zeros(1, 2, 16000))                                      # CPU tensor: no fallback
     with pytest.raises(ValueError):
         net_e(torch.zeros(1, 2, 100, device=DEV))
+
+
+def test_embedder_half_batches_on_two_streams_are_bit_identical(embedder):
+    """`EmbedTFGridNet.n_streams` = 2 (the default from 32 utterances on): two half-batches on two HIP streams, whose kernels
+    fill each other's ragged last rounds of workgroups.  Utterances are independent, so the embeddings must equal the
+    single-stream ones bit for bit (same kernels, same per-utterance reduction orders) — also with the unfused round-1 axis
+    kernels (`fused_axis` off) as the reference of the fused path at a batch size only this test uses."""
+    net_e, _, _ = embedder
+    x = synth.batch(list(range(4)), 24000)["mixture"].repeat(8, 1, 1).contiguous().to(DEV)      # 32 utterances x 1.5 s
+    keep = net_e.n_streams
+    try:
+        net_e.n_streams = 1
+        one = net_e(x)
+        net_e.n_streams = 2
+        for _ in range(3):
+            assert torch.equal(net_e(x), one)
+        net_e.n_streams, net_e.fused_axis = 1, False
+        old = net_e(x)
+        assert _err(old, one.cpu()) < 2e-5
+    finally:
+        net_e.n_streams, net_e.fused_axis = keep, True
