@@ -53,6 +53,11 @@ def evaluate(model: Callable, data_fn: Callable[[List[int]], dict], n_utts: int,
                 o, i, c = per_utterance(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
             rows += [dict(idx=k, output_sisnr=float(a), si_snr_i=float(b), embedding_sim=float(e))
                      for k, a, b, e in zip(idx, o.tolist(), i.tolist(), c.tolist())]
+    # range guard (include/lookonce_hip.h): a Net checks its flag when the NEXT forward starts; after the last batch ask it
+    net = getattr(model, "__self__", model)                  # a bound method (net.forward) or the module itself
+    if callable(getattr(net, "range_status", None)) and getattr(net, "_range_flags", None):
+        if any(net.range_status(dev_key) for dev_key in list(net._range_flags)):
+            raise RuntimeError("LH_ERR_RANGE: the last batch produced non-finite samples (stored as 0): inf / NaN in the input")
     if dist is not None and world > 1:
         dist.all_reduce(total)                               # sum over ranks, 32 bytes
     n = max(float(total[3].item()), 1.0)

@@ -156,12 +156,15 @@ class Net(nn.Module):
         self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
         # range guard of the split-precision kernels (include/lookonce_hip.h): the frame kernels scale every row / tile by
         # a power of two before they split it, so any finite input is in range; non-finite output samples (inf / NaN in
-        # the input, a true fp32 overflow) are stored as 0 and raise THIS Net's flag word (`_range_flag`, one per device,
-        # never shared with another Net or a Streamer).  With `range_check` every forward ends with lh_range_status (an
-        # exchange kernel + 4-byte copy + a wait on the launch stream) and raises; a `Streamer` polls its own flag.
-        # The check is skipped while the stream is being captured into a HIP graph (a wait is illegal there): poll
-        # `net.range_status(stream)` after the replay instead.
-        self.range_check = os.environ.get("LOOKONCE_RANGE_CHECK", "1") != "0"
+        # the input, a true fp32 overflow) are stored as 0 and raise THIS Net's flag word (`_range_flag`: pinned host
+        # memory the kernel stores to directly, one per device, never shared with another Net or a Streamer).
+        #   range_check = True / "deferred" (default): the forward stays asynchronous; the word is looked at when the NEXT
+        #       forward starts and in `range_status()`, and a set word raises LH_ERR_RANGE there.  (Round 3 ended every
+        #       forward with a host wait: 7.58 -> 7.36 ms per batch-32 step without it, profiles/r04e.)
+        #   range_check = "sync": wait for the stream at the end of every forward and raise from the forward that
+        #       produced the samples (LOOKONCE_RANGE_CHECK=sync); False / LOOKONCE_RANGE_CHECK=0: never look.
+        rc = os.environ.get("LOOKONCE_RANGE_CHECK", "1")
+        self.range_check = False if rc == "0" else ("sync" if rc == "sync" else True)
         self._range_flags: Dict[str, torch.Tensor] = {}
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
@@ -300,25 +303,30 @@ class Net(nn.Module):
         return ws
 
     def _range_flag(self, device) -> torch.Tensor:
-        """This Net's two-word range flag on `device` (include/lookonce_hip.h: [0] sticky, [1] last fetched value)."""
+        """This Net's two-word range flag for `device` (include/lookonce_hip.h: [0] sticky, [1] unused here): pinned host
+        memory on the GPU path — device-accessible, and readable by the host without a copy or a launch."""
         key = str(device)
         if key not in self._range_flags:
-            self._range_flags[key] = torch.zeros(2, dtype=torch.int32, device=device)
+            t = torch.zeros(2, dtype=torch.int32)
+            self._range_flags[key] = t.pin_memory() if torch.device(device).type == "cuda" else t
         return self._range_flags[key]
 
     def range_status(self, device=None) -> bool:
-        """Fetch-and-clear this Net's range flag on the current stream of `device` (waits for the stream).  True when a
-        forward since the last check stored a zero in place of a non-finite sample.  For callers that run with
-        `range_check = False` or replay the forward from a HIP graph."""
-        dev = torch.device(device) if device is not None else next(iter(self._range_flags.values())).device
+        """Waits for the current stream of `device`, then reads and clears this Net's range flag: True when a forward since
+        the last look stored zeros in place of non-finite samples.  Call it after the last forward of a loop (a set flag
+        otherwise raises at the start of the next forward)."""
+        dev = torch.device(device) if device is not None else torch.device(next(iter(self._range_flags)))
         flag = self._range_flag(dev)
-        lib = self._lib(flag)
-        with _device_of(flag):
-            st = torch.cuda.current_stream(dev).cuda_stream if flag.is_cuda else 0
-            rc = lib.raw("lh_range_status")(flag.data_ptr(), st)
-        if rc not in (0, 4):
-            raise RuntimeError(f"lh_range_status failed: {_cabi.ERRORS.get(rc, rc)}")
-        return rc == 4
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        bad = int(flag[0]) != 0
+        if bad:
+            flag.zero_()
+        return bad
+
+    _RANGE_MSG = ("LH_ERR_RANGE: {} produced non-finite samples (stored as 0). The frame kernels scale every row by a power of "
+                  "two before the fp16 hi + lo split, so this means inf / NaN in the input or the state, or an activation "
+                  "beyond the fp32 range itself (include/lookonce_hip.h, range contract).")
 
     def _zero_state(self, B, device) -> dict:
         key = (B, str(device))
@@ -335,6 +343,9 @@ class Net(nn.Module):
                                ".eval() and/or run under torch.no_grad(); training stays on the reference model")
         lib = self._lib(x)
         dev = x.device
+        if self.range_check and int(self._range_flag(dev)[0]) != 0:       # deferred look at the previous forwards' flag: a host read
+            self._range_flag(dev).zero_()
+            raise RuntimeError(self._RANGE_MSG.format("an earlier forward of this Net"))
         hop, nfft = self.stft_chunk_size, self.nfft
         assert x.dim() == 3 and x.shape[1] == self.num_ch, "input must be [B, num_ch, N]"
         Bn, _, n = x.shape
@@ -464,20 +475,10 @@ class Net(nn.Module):
                      P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), P(flag), Bn, T, st)
             if want_state:
                 state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
-            if self.range_check and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
-                self._raise_on_range(lib_, flag, st)
+            if self.range_check == "sync" and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+                if self.range_status(dev):
+                    raise RuntimeError(self._RANGE_MSG.format("this forward"))
         return y, (state if want_state else None)
-
-    @staticmethod
-    def _raise_on_range(lib, flag, stream):
-        rc = lib.raw("lh_range_status")(flag.data_ptr(), stream)
-        if rc == 4:
-            raise RuntimeError(
-                "LH_ERR_RANGE: the forward produced non-finite samples (stored as 0). The frame kernels scale every row by a "
-                "power of two before the fp16 hi + lo split, so this means inf / NaN in the input or the state, or an "
-                "activation beyond the fp32 range itself (include/lookonce_hip.h, range contract).")
-        if rc != 0:
-            raise RuntimeError(f"lh_range_status failed: {_cabi.ERRORS.get(rc, rc)}")
 
     # ------------------------------------------------------------------------------------------------
     # streaming fast path (Streamer)

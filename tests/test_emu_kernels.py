@@ -310,8 +310,9 @@ def test_any_finite_input_scale_matches_the_oracle(emu_net, oracle_cfg_sd):
 
 def test_range_guard_is_per_caller_and_emits_silence(emu_net, oracle_cfg_sd):
     """Range guard (include/lookonce_hip.h): a NaN / inf that reaches the back end is stored as 0 and raises the CALLER's
-    flag word — `Net.forward` raises LH_ERR_RANGE, the exchange clears the flag (next forward clean), and a second Net or a
-    Streamer on the same device keeps its own word: it neither sees nor clears the first one's flag."""
+    flag word.  `Net` looks at its own word when its NEXT forward starts (the forward itself stays asynchronous) and in
+    `range_status()`; `range_check = "sync"` raises from the offending forward.  A second Net or a Streamer on the same
+    device keeps its own word: it neither sees nor clears the first one's flag."""
     cfg, sd = oracle_cfg_sd
     d = synth.batch([1], 128 * 3)
     bad = d["mixture"].clone()
@@ -319,18 +320,22 @@ def test_range_guard_is_per_caller_and_emits_silence(emu_net, oracle_cfg_sd):
     other = Net(**O.TSH_PARAMS).eval()
     other.load_state_dict(sd, strict=True)
     other._lib_override = emu_net._lib_override
-    emu_net.range_check = False
+    y = emu_net(bad, d["embedding_gt"])                    # flag raised, not consumed
+    assert torch.isfinite(y).all() and (y == 0).any()      # silence instead of NaN
+    yo = other(d["mixture"], d["embedding_gt"])            # the other Net must not see (or clear) it
+    assert torch.isfinite(yo).all() and other.range_status("cpu") is False
+    assert emu_net.range_status("cpu") is True             # still pending for its owner ...
+    assert emu_net.range_status("cpu") is False            # ... and cleared by the look
+    emu_net(bad, d["embedding_gt"])
+    with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):    # deferred: the next forward of the same Net raises
+        emu_net(d["mixture"], d["embedding_gt"])
+    assert torch.equal(emu_net(d["mixture"], d["embedding_gt"]), yo)
+    emu_net.range_check = "sync"
     try:
-        y = emu_net(bad, d["embedding_gt"])                # flag raised, not consumed
+        with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
+            emu_net(bad, d["embedding_gt"])
     finally:
         emu_net.range_check = True
-    assert torch.isfinite(y).all() and (y == 0).any()      # silence instead of NaN
-    yo = other(d["mixture"], d["embedding_gt"])            # the other Net's check must not see (or clear) it
-    assert torch.isfinite(yo).all()
-    assert emu_net.range_status("cpu") is True             # still pending for its owner ...
-    assert emu_net.range_status("cpu") is False            # ... and cleared by the fetch
-    with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
-        emu_net(bad, d["embedding_gt"])
     assert torch.equal(emu_net(d["mixture"], d["embedding_gt"]), yo)
     st = emu_net.make_streamer(1, "cpu", use_graph=False)
     st.set_embedding(d["embedding_gt"][:, 0])
@@ -343,6 +348,10 @@ def test_range_guard_is_per_caller_and_emits_silence(emu_net, oracle_cfg_sd):
     st.reset()
     assert torch.isfinite(st.step(d["mixture"][:, :, :192])).all()
     assert emu_net._lib_override.raw("lh_selftest_fp16_subnormal")(None) == 0
+    # the C-ABI's own fetch-and-clear (hosts without Python): one exchange, then clean
+    flag = torch.ones(2, dtype=torch.int32)
+    assert emu_net._lib_override.raw("lh_range_status")(flag.data_ptr(), None) == 4
+    assert emu_net._lib_override.raw("lh_range_status")(flag.data_ptr(), None) == 0 and int(flag[0]) == 0
 
 
 def test_cabi_argument_errors(emu_net):

@@ -143,8 +143,9 @@ def test_fp16_range_stress_of_the_split_precision_path(oracle_cfg_sd):
         peak = max(float(v.abs().max()) for k, v in taps.items() if k.endswith(".out") or k == "Z0")
         res = {}
         for mode in ("f16x3", "f32rec"):
-            y = _make(sds, gemm=mode)(x.to(DEV), e.to(DEV))           # raises LH_ERR_RANGE on a non-finite sample
-            assert torch.isfinite(y).all()
+            net_s = _make(sds, gemm=mode)
+            y = net_s(x.to(DEV), e.to(DEV))
+            assert not net_s.range_status(DEV) and torch.isfinite(y).all()
             res[mode] = _err(y, yo) / amp
         rows.append(dict(scale=s, residual_peak=peak, out_amp=amp, rel_err_f16x3=res["f16x3"], rel_err_f32rec=res["f32rec"]))
         print(rows[-1])
@@ -176,8 +177,10 @@ def test_mixture_scale_quiet_and_hot_recordings(nets, oracle_cfg_sd):
 
 def test_range_flag_belongs_to_its_caller(oracle_cfg_sd):
     """ADVICE r3 (medium) / VERDICT r3 weak item 2: two Nets on two streams of ONE device, one of them fed a NaN.  Only
-    that one raises, its output holds zeros instead of NaN, and the healthy Net's output is bit-identical to running alone
-    (the flag word is per caller since ABI 12; a Streamer owns a third one)."""
+    that one's flag is raised, its output holds zeros instead of NaN, and the healthy Net's output is bit-identical to
+    running alone (the flag word is per caller since ABI 12: pinned host memory the back end stores to directly; a Streamer
+    owns a third one).  Forwards stay asynchronous: the owner raises when its NEXT forward starts, or says so in
+    `range_status()`; `range_check = "sync"` raises from the offending forward."""
     cfg, sd = oracle_cfg_sd
     a, b = _make(sd), _make(sd)
     d = synth.batch(list(range(90, 98)), 32000)
@@ -185,7 +188,6 @@ def test_range_flag_belongs_to_its_caller(oracle_cfg_sd):
     bad = x.clone()
     bad[3, 1, 5000] = float("nan")
     alone = b(x, e).clone()
-    a.range_check = b.range_check = False                  # no host wait inside the forwards: both queues stay busy
     s1, s2 = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
     torch.cuda.synchronize()
     for rep in range(3):
@@ -197,13 +199,19 @@ def test_range_flag_belongs_to_its_caller(oracle_cfg_sd):
         assert torch.isfinite(ya).all() and bool((ya[3] == 0).any())
         assert torch.equal(yb, alone)
         with torch.cuda.stream(s2):
-            assert b.range_status(DEV) is False            # the healthy Net polls first: must not see or clear a's flag
+            assert b.range_status(DEV) is False            # the healthy Net looks first: must not see or clear a's flag
         with torch.cuda.stream(s1):
             assert a.range_status(DEV) is True
             assert a.range_status(DEV) is False
-    a.range_check = True
+    a(bad, e)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):    # deferred: raised when the next forward starts
+        a(x, e)
+    assert torch.equal(a(x, e), alone)
+    a.range_check = "sync"
     with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
         a(bad, e)
+    a.range_check = True
     st = a.make_streamer(1, DEV)
     st.set_embedding(e[:1, 0])
     for i in range(10):
@@ -217,6 +225,14 @@ def test_range_flag_belongs_to_its_caller(oracle_cfg_sd):
     assert int(st.range_flag[0]) == 1 and a.range_status(DEV) is False
     with pytest.raises(RuntimeError, match="LH_ERR_RANGE"):
         st.step(x[:1, :, :192])
+    # the C ABI's fetch-and-clear on a DEVICE word (hosts without Python)
+    flag = torch.zeros(2, dtype=torch.int32, device=DEV)
+    lib = _cabi.load()
+    stream = torch.cuda.current_stream(DEV).cuda_stream
+    assert lib.raw("lh_range_status")(flag.data_ptr(), stream) == 0
+    flag[0] = 1
+    assert lib.raw("lh_range_status")(flag.data_ptr(), stream) == 4
+    assert lib.raw("lh_range_status")(flag.data_ptr(), stream) == 0
 
 
 def test_stage_taps_are_bit_reproducible(nets):
@@ -317,7 +333,6 @@ def test_two_forwards_on_two_streams_are_bit_identical(oracle_cfg_sd):
     _, sd = oracle_cfg_sd
     nets2 = [_make(sd), _make(sd)]
     for n in nets2:
-        n.range_check = False                      # no host wait inside the forward: both streams must be fed back to back
     d = synth.batch(list(range(60, 68)), 80000)
     mix = d["mixture"].repeat(4, 1, 1).to(DEV)
     emb = d["embedding_gt"].repeat(4, 1, 1).to(DEV)
@@ -350,7 +365,6 @@ def test_batch1_forward_next_to_a_batched_forward_is_bit_identical(oracle_cfg_sd
     _, sd = oracle_cfg_sd
     nets2 = [_make(sd), _make(sd)]
     for n in nets2:
-        n.range_check = False
     d = synth.batch(list(range(70, 86)), 80000)
     big = (d["mixture"].to(DEV), d["embedding_gt"].to(DEV))
     one = (d["mixture"][3:4].contiguous().to(DEV), d["embedding_gt"][3:4].contiguous().to(DEV))
