@@ -332,7 +332,6 @@ def test_two_forwards_on_two_streams_are_bit_identical(oracle_cfg_sd):
     stream shared their CU: 1e-2 errors in 11 of 12 launches) — the library is built without packed fp32 now."""
     _, sd = oracle_cfg_sd
     nets2 = [_make(sd), _make(sd)]
-    for n in nets2:
     d = synth.batch(list(range(60, 68)), 80000)
     mix = d["mixture"].repeat(4, 1, 1).to(DEV)
     emb = d["embedding_gt"].repeat(4, 1, 1).to(DEV)
@@ -364,7 +363,6 @@ def test_batch1_forward_next_to_a_batched_forward_is_bit_identical(oracle_cfg_sd
     the unsafe packed form lost lanes 48..63) runs on another: the batch-1 output must equal the same forward run alone."""
     _, sd = oracle_cfg_sd
     nets2 = [_make(sd), _make(sd)]
-    for n in nets2:
     d = synth.batch(list(range(70, 86)), 80000)
     big = (d["mixture"].to(DEV), d["embedding_gt"].to(DEV))
     one = (d["mixture"][3:4].contiguous().to(DEV), d["embedding_gt"][3:4].contiguous().to(DEV))
