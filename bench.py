@@ -716,6 +716,9 @@ def main():
         elapsed, local_elapsed, (y, sums) = timed_region(step, args.steps, dist, dev, torch.cuda.synchronize)
         prof, net._prof, net._prof_only = net._prof, None, None
     log(f"timed region: {local_elapsed * 1e3 / args.steps:.3f} ms/step (max over ranks {elapsed * 1e3 / args.steps:.3f})")
+    # the forwards ran asynchronously (deferred range check, net.py): one look at this Net's flag word for the whole region
+    range_flag_raised = bool(net.range_status(dev)) if net.range_check else None
+    assert not range_flag_raised, "LH_ERR_RANGE: a timed forward stored zeros in place of non-finite samples"
     # N > 1: the exchange step by itself — 100 all-reduces of the 32-byte metric vector on RCCL, HIP events on this rank
     allreduce_us, ranks_seen = None, world
     if dist is not None:
@@ -807,6 +810,7 @@ def main():
             "roofline": roof,
             "power": power,
             "n_ranks_seen": ranks_seen, "allreduce_32B_us": allreduce_us,
+            "range_check": {"mode": "deferred" if net.range_check is True else net.range_check, "flag_raised": range_flag_raised},
             # ms per step of each C-ABI call: the dominant one live over the timed region, the rest from the instrumented
             # warm-up step
             "kernels_ms_per_step": {k: v["avg_ms"] * breakdown[k]["launches"]
