@@ -1194,28 +1194,23 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
     const long a_off0 = (long)min(m0 + sr, M - 1) * lda + sb * 8, a_off1 = (long)min(m0 + sr + 64, M - 1) * lda + sb * 8;
     const long b_off0 = (long)min(n0 + sr, N - 1) * ldb + sb * 8, b_off1 = (long)min(n0 + sr + 64, N - 1) * ldb + sb * 8;
     const int s_idx0 = (sb * GM_RP + sr) * 8, s_idx1 = (sb * GM_RP + sr + 64) * 8;
-    // global -> register staging TWO k-steps ahead (two register sets): one k-step is ~1000-1600 cycles of MFMA work per SIMD,
-    // an HBM round trip under load is longer, and with a single set every stage ended up waiting for its own loads
-    f16x8 stA[8], stB[8];
-    auto fetch = [&](int k0, f16x8 (&st)[8]) {
-        k0 = min(k0, K - 32);                  // (past the end: a cached re-load of the last step, never stored)
+    f16x8 st[8];
+    auto fetch = [&](int k0) {
         st[0] = *reinterpret_cast<const f16x8*>(Ab + a_off0 + k0);        st[1] = *reinterpret_cast<const f16x8*>(Ab + a_off1 + k0);
         st[2] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off0 + k0); st[3] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off1 + k0);
         st[4] = *reinterpret_cast<const f16x8*>(Bb + b_off0 + k0);        st[5] = *reinterpret_cast<const f16x8*>(Bb + b_off1 + k0);
         st[6] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off0 + k0); st[7] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off1 + k0);
     };
-    // ONE accumulator per 16 x 16 tile for the three partial products (the un-rescaled split allows it): the 64 registers of the
-    // second set hold the deeper prefetch instead; a tile's three MFMAs are issued four instructions apart
-    f32x4 am[4][4];
+    f32x4 am[4][4], ac[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn) am[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jn = 0; jn < 4; ++jn) { am[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    fetch(0);
     const int nk = K / 32;
     const int jn_live = min(4, max(0, (N - (n0 + wn * 64) + 15) / 16));      // 16-column sub-tiles of this wave with any column < N
-    fetch(0, stA);
-    fetch(32, stB);
-    auto stage = [&](int ks, f16x8 (&st)[8]) {
+#pragma unroll 1
+    for (int ks = 0; ks < nk; ++ks) {
         _Float16* buf = &sm[ks & 1][0][0];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1223,7 +1218,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
             *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx1]) = st[2 * i + 1];
         }
         __syncthreads();
-        fetch((ks + 2) * 32, st);                       // unconditional (clamped): the compiler can count the loads in flight
+        if (ks + 1 < nk) fetch((ks + 1) * 32);
         f16x8 bh[4], bl[4];
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) {
@@ -1236,25 +1231,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
             const int idx = (g4 * GM_RP + wm * 64 + i * 16 + l15) * 8;
             const f16x8 ah = *reinterpret_cast<const f16x8*>(&buf[idx]);
             const f16x8 al = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
-            // (jn < jn_live is wave-uniform: N = 1040 leaves 112 of the last tile's 128 columns empty — no MFMAs for those)
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn)
-                if (jn < jn_live) am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn)
-                if (jn < jn_live) am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], am[i][jn], 0, 0, 0);
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn)
-                if (jn < jn_live) am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], am[i][jn], 0, 0, 0);
+            for (int jn = 0; jn < 4; ++jn) {
+                if (jn < jn_live) {      // (wave-uniform) N = 1040 leaves 112 of the last tile's 128 columns empty: no MFMAs for those
+                    am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
+                    ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], ac[i][jn], 0, 0, 0);
+                    ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], ac[i][jn], 0, 0, 0);
+                }
+            }
         }
-    };
-    int ks = 0;
-#pragma unroll 1
-    for (; ks + 1 < nk; ks += 2) {
-        stage(ks, stA);
-        stage(ks + 1, stB);
     }
-    if (ks < nk) stage(ks, stA);
     // epilogue: lane holds rows g4*4 + r, column l15 of each 16 x 16 tile -> 64-byte row segments
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1265,7 +1251,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * 64 + i * 16 + g4 * 4 + r;
                 if (row < M && col < N) {
-                    const float val = am[i][jn][r] * scale;
+                    const float val = (am[i][jn][r] + ac[i][jn][r] * (1.0f / ESPLIT)) * scale;
                     if (EPI == 0) {
                         Cm[(long)batch * strideC + (long)row * ldc + col] = val;
                     } else {                     // batch = h*Bn + b, row = frame, col = f*16 + v
