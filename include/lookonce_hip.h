@@ -216,19 +216,6 @@ int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const fl
                    const float* lnv_b, void* q, void* kx, void* vx, const int* ring_pos, int B, int T,
                    lh_stream_t stream);
 
-/* Streaming (one frame per chunk, T = 1): lh_linear_res (the intra Linear + residual), lh_inter_block and lh_qkv_proj_ln of
- * one block as ONE launch — the frame stays on its CU between the three (tfgridnet_causal.py:513-562 for a single frame).
- *   xa [B][97][64] the intra path's input; hbuf [B*97][128] lh_intra_stream's hidden states; wlin1_pk / blin1 = lh_linear_res's
- *   arguments for K = 128; wgate_pk fp16 image [4 waves][4 gates][4 ksteps][64 lanes][hi 8 | lo 8] of [W_ih * ln_w | W_hh] with
- *   b_gate [256] (weights.py pack_lstm_f16x3 / `inter_b16`: gate rows pre-scaled, LayerNorm affine folded); wlin2_pk / blin2 =
- *   lh_inter_block's wlin_pk / blin; h0, c0 -> hN, cN [B*97][64] (no alias); xc [B][97][64] out (the projection's residual);
- *   the remaining arguments are lh_qkv_proj_ln's (ring_pos as there) */
-int lh_stream_mid(const float* xa, const float* hbuf, const void* wlin1_pk, const float* blin1, const void* wgate_pk,
-                  const float* bgate, const void* wlin2_pk, const float* blin2, const float* h0, const float* c0, float* hN,
-                  float* cN, float* xc, const void* wqkv_pk, const float* bqkv, const float* slopes, const float* lnq_w,
-                  const float* lnq_b, const float* lnk_w, const float* lnk_b, const float* lnv_w, const float* lnv_b, void* q,
-                  void* kx, void* vx, const int* ring_pos, int B, lh_stream_t stream);
-
 /* A.3.5  local windowed attention over exactly 50 slots (frames t-49..t incl. history rows, no mask) with
  * the head merge fused into the store.  Replaces tfgridnet_causal.py:564-581 without materialising the
  * 50x unfolded K/V (`_causal_unfold_chunk`, :429-454).

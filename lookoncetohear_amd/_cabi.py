@@ -29,7 +29,6 @@ SIGNATURES = {
     "lh_inter_block": [_P] * 10 + [_I, _I, _P],
     "lh_linear_res": [_P] * 5 + [_I, _I, _P],
     "lh_qkv_proj_ln": [_P] * 14 + [_I, _I, _P],
-    "lh_stream_mid": [_P] * 26 + [_I, _P],
     "lh_local_attn": [_P] * 4 + [_I, _I, _P],
     "lh_ring_pack": [_P] * 4 + [_I, _I, _P],
     "lh_ring_unpack": [_P] * 4 + [_I, _I, _P],

@@ -185,43 +185,17 @@ __device__ unsigned long long lh_qkv_trace_buf[16];
 #define QKV_STAMP(k) do { } while (0)
 #endif
 
-// Streaming (one frame per chunk): what runs between the intra LSTM and the attention of a block — intra Linear + residual,
-// the whole inter path (LayerNorm, ONE LSTM step per (utterance, bin) with carried state, Linear + residual) and this
-// kernel's Q/K/V — was three launches of ~5-8 us each, two of them near the floor of a graph node.  With MID the workgroup
-// produces its frame itself before the Q/K/V part (reference tfgridnet_causal.py:513-538 for T = 1) and the frame never
-// leaves the CU in between:  xb = x + b1 + W1 [h_f | h_r];  gates = [LN(xb) | h0] [W_ih' | W_hh]^T + b;  (h, c) = cell;
-// y = xb + b2 + W2 h  (written out: the projection's residual)  ->  Q/K/V of y.
-struct MidArgs {
-    const float* xa;            // [nframes][97][64]  input of the intra path (residual of its Linear)
-    const float* hbuf;          // [nframes*97][128]  intra hidden states (forward | reverse), lh_intra_stream's output
-    const _Float16* wlin1;      // intra_linear image [4 ntiles][4 ksteps][64][16];  blin1 [64]
-    const float* blin1;
-    const _Float16* wg;         // inter LSTM image [4 waves][4 gates][4 ksteps][64][hi 8 | lo 8] (weights.py pack_lstm_f16x3 of
-    const float* bg;            //   [W_ih * ln_w | W_hh], gate rows pre-scaled); bg [256] = (i, f, g, o) x 64, same scaling
-    const _Float16* wlin2;      // inter_linear image [4][2][64][16];  blin2 [64]
-    const float* blin2;
-    const float* h0;            // [nframes*97][64] carried state in / out (must not alias)
-    const float* c0;
-    float* hN;
-    float* cN;
-    float* xc;                  // [nframes][97][64] out: the frame after the inter path
-};
-constexpr int MID_A = 4 * 4 * FR_RP * 8;       // halves per A image with K = 128
-constexpr int MID_XP = C + 4;                  // fp32 frame rows in LDS
-
-template <bool MID>
-__global__ void __launch_bounds__(256, MID ? 1 : 2) k_qkv_proj_ln(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
+__global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict__ y, const _Float16* __restrict__ w_pk,
                                                      const float* __restrict__ bias, const float* __restrict__ slopes,
                                                      const float* __restrict__ lnq_w, const float* __restrict__ lnq_b,
                                                      const float* __restrict__ lnk_w, const float* __restrict__ lnk_b,
                                                      const float* __restrict__ lnv_w, const float* __restrict__ lnv_b,
                                                      _Float16* __restrict__ q, _Float16* __restrict__ kx,
                                                      _Float16* __restrict__ vx, int T, int nframes,
-                                                     const int* __restrict__ ring_pos, MidArgs mid) {
-    __shared__ __attribute__((aligned(16))) _Float16 ahi[MID ? MID_A : FR_A];
-    __shared__ __attribute__((aligned(16))) _Float16 alo[MID ? MID_A : FR_A];
+                                                     const int* __restrict__ ring_pos) {
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float yf[Y_N];
-    __shared__ __attribute__((aligned(16))) float xbuf[MID ? NF * MID_XP : 4];
     // the input is the un-normalised residual stream: every row is scaled by its own power of two before the split and
     // the accumulator rows by the inverse (frame_store_scaled, lh_split.h) — Linear is linear, the bias joins afterwards
     __shared__ __attribute__((aligned(16))) float rinv[FR_RP];
@@ -249,11 +223,7 @@ __global__ void __launch_bounds__(256, MID ? 1 : 2) k_qkv_proj_ln(const float* _
     for (int i = tid; i < 2 * NH * (YQS - DQK); i += 256)      // pad entries 582.. of the Q / K heads stay zero
         yf[(i / (YQS - DQK)) * YQS + DQK + i % (YQS - DQK)] = 0.f;
     float4 stg[FR_NLD];
-    if (!MID && (int)blockIdx.x < nframes) frame_load(y + (long)blockIdx.x * NF * C, tid, stg);
-    if constexpr (MID) {                                   // pad rows 97..111 of the K = 128 image: finite, once
-        for (int e = tid; e < (FR_RP - NF) * 32; e += 256)
-            store_split4<FR_RP>(ahi, alo, NF + (e >> 5), (e & 31) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
-    }
+    if ((int)blockIdx.x < nframes) frame_load(y + (long)blockIdx.x * NF * C, tid, stg);
     const long tkp = T + HIST + KV_PAD;
     // K / V row of frame t: HIST + t behind the history rows — or, for a one-frame chunk on a persistent ring
     // (ring_pos != NULL, T = 1), slot (*ring_pos mod 50): the 50 rows are then exactly the attention window, in
@@ -262,149 +232,10 @@ __global__ void __launch_bounds__(256, MID ? 1 : 2) k_qkv_proj_ln(const float* _
     for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
         const int b = fr / T, t = fr % T;
         QKV_STAMP(0);
-        if constexpr (MID) {
-            _Float16* const hhi = reinterpret_cast<_Float16*>(yf);      // h image (K = 64) lives in yf until the Q/K/V epilogue needs it
-            _Float16* const hlo = hhi + FR_A;
-            static_assert(2 * FR_A * sizeof(_Float16) <= Y_N * sizeof(float), "h image must fit in yf");
-            const long r0 = (long)fr * NF;                              // first row of the frame (T = 1: row = sequence b*97 + f)
-            __syncthreads();                                            // previous frame's LayerNorm reads of yf / xbuf users done
-            // P0: xbuf <- x rows; A image <- split(h rows) (K = 128: bounded values, no scaling); h image pad rows <- 0
-            {
-                float4 xv[FR_NLD];
-                frame_load(mid.xa + r0 * C, tid, xv);
-#pragma unroll
-                for (int i = 0; i < FR_NLD; ++i) {
-                    const int e = tid + 256 * i;
-                    if (e < NF * 16) *reinterpret_cast<float4*>(&xbuf[(e >> 4) * MID_XP + (e & 15) * 4]) = xv[i];
-                }
-                constexpr int NH4 = (NF * 32 + 255) / 256;              // 13 float4 of h per thread
-#pragma unroll
-                for (int i = 0; i < NH4; ++i) {
-                    const int e = tid + 256 * i;
-                    if (e < NF * 32)
-                        store_split4<FR_RP>(ahi, alo, e >> 5, (e & 31) * 4,
-                                            *reinterpret_cast<const float4*>(&mid.hbuf[(r0 + (e >> 5)) * (2 * H) + (e & 31) * 4]));
-                }
-                for (int e = tid; e < (FR_RP - NF) * 16; e += 256) {
-                    const int idx = a_index<FR_RP>(NF + (e >> 4), (e & 15) * 4);
-                    *reinterpret_cast<f16x4*>(&hhi[idx]) = f16x4{0, 0, 0, 0};
-                    *reinterpret_cast<f16x4*>(&hlo[idx]) = f16x4{0, 0, 0, 0};
-                }
-            }
-            __syncthreads();
-            // P1: xb = x + b1 + W1 h   (wave w owns output channels 16w .. 16w+15)
-            {
-                f16x8 wh[4], wl[4];
-                load_w<4>(mid.wlin1, wave, lane, wh, wl);
-                const float bz = mid.blin1[wave * 16 + l15];
-#pragma unroll 1
-                for (int m = 0; m < FR_RP / 16; ++m) {
-                    const f32x4 acc = mma_tile<FR_RP, 4>(ahi, alo, m, g4, l15, wh, wl, bz);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = m * 16 + g4 * 4 + r;
-                        if (row < NF) xbuf[row * MID_XP + wave * 16 + l15] += acc[r];
-                    }
-                }
-            }
-            __syncthreads();
-            // P2: A image <- [ split(LN(xb)) | split(h0) ]  (LayerNorm affine folded into the gate weights)
-#pragma unroll
-            for (int i = 0; i < FR_NLD; ++i) {
-                const int e = min(tid + 256 * i, NF * 16 - 1), row = e >> 4, c4 = e & 15;
-                float4 u = *reinterpret_cast<const float4*>(&xbuf[row * MID_XP + c4 * 4]);
-                const float mean = group16_sum(u.x + u.y + u.z + u.w) * (1.0f / C);
-                u.x -= mean; u.y -= mean; u.z -= mean; u.w -= mean;
-                const float var = group16_sum(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w) * (1.0f / C);
-                const float rstd = rsqrtf(var + LN_EPS);
-                if (tid + 256 * i < NF * 16) {
-                    store_split4<FR_RP>(ahi, alo, row, c4 * 4, make_float4(u.x * rstd, u.y * rstd, u.z * rstd, u.w * rstd));
-                    store_split4<FR_RP>(ahi, alo, row, C + c4 * 4, *reinterpret_cast<const float4*>(&mid.h0[(r0 + row) * H + c4 * 4]));
-                }
-            }
-            __syncthreads();
-            // P3: gates (wave w: hidden units 16w .. 16w+15, the four gates as its four column tiles -> lane-local cell), cell,
-            // new state out, h -> h image
-            {
-                f16x8 gh[4][4], gl[4][4];
-                float gb[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const _Float16* p = mid.wg + ((long)((wave * 4 + g) * 4 + ks) * 64 + lane) * 16;
-                        gh[g][ks] = *reinterpret_cast<const f16x8*>(p);
-                        gl[g][ks] = *reinterpret_cast<const f16x8*>(p + 8);
-                    }
-                    gb[g] = mid.bg[g * H + wave * 16 + l15];
-                }
-                const int unit = wave * 16 + l15;
-#pragma unroll 1
-                for (int m = 0; m < FR_RP / 16; ++m) {
-                    float cprev[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cprev[r] = mid.c0[(r0 + min(m * 16 + g4 * 4 + r, NF - 1)) * H + unit];
-                    f32x4 acc[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = f32x4{gb[g], gb[g], gb[g], gb[g]};
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int idx = a_slot<FR_RP>(ks * 4 + g4, m * 16 + l15);
-                        const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
-                        const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, gh[g][ks], acc[g], 0, 0, 0);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, gl[g][ks], acc[g], 0, 0, 0);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, gh[g][ks], acc[g], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = m * 16 + g4 * 4 + r;
-                        float c = cprev[r], hv;
-                        lstm_cell_pre(acc[0][r], acc[1][r], acc[2][r], acc[3][r], c, hv);
-                        if (row < NF) {
-                            mid.cN[(r0 + row) * H + unit] = c;
-                            mid.hN[(r0 + row) * H + unit] = hv;
-                            _Float16 th, tl;
-                            split_hl(hv, th, tl);
-                            const int idx = a_index<FR_RP>(row, unit);
-                            hhi[idx] = th;
-                            hlo[idx] = tl;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // P4: y = xb + b2 + W2 h
-            {
-                f16x8 wh[2], wl[2];
-                load_w<2>(mid.wlin2, wave, lane, wh, wl);
-                const float bz = mid.blin2[wave * 16 + l15];
-#pragma unroll 1
-                for (int m = 0; m < FR_RP / 16; ++m) {
-                    const f32x4 acc = mma_tile<FR_RP, 2>(hhi, hlo, m, g4, l15, wh, wl, bz);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = m * 16 + g4 * 4 + r;
-                        if (row < NF) xbuf[row * MID_XP + wave * 16 + l15] += acc[r];
-                    }
-                }
-            }
-            __syncthreads();
-            // P5: the frame leaves (the projection's residual) and becomes this kernel's staged input
-#pragma unroll
-            for (int i = 0; i < FR_NLD; ++i) {
-                const int e = min(tid + 256 * i, NF * 16 - 1);
-                stg[i] = *reinterpret_cast<const float4*>(&xbuf[(e >> 4) * MID_XP + (e & 15) * 4]);
-                if (tid + 256 * i < NF * 16) *reinterpret_cast<float4*>(&mid.xc[r0 * C + (long)e * 4]) = stg[i];
-            }
-        }
         frame_store_scaled(ahi, alo, rinv, tid, stg);
         __syncthreads();                      // image complete; also orders the previous frame's reads of `yf`
         QKV_STAMP(1);
-        if (!MID && fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
+        if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
         // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check
         auto row_tile = [&](int m, auto checked) {
@@ -630,29 +461,9 @@ extern "C" int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bia
         !vx || B <= 0 || T <= 0 || (ring_pos && T != 1))
         return LH_ERR_ARG;
     const int nframes = B * T;
-    hipLaunchKernelGGL((k_qkv_proj_ln<false>), dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y,
+    hipLaunchKernelGGL(k_qkv_proj_ln, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y,
                        (const _Float16*)w_pk, bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, (_Float16*)q,
-                       (_Float16*)kx, (_Float16*)vx, T, nframes, ring_pos, MidArgs{});
-    return check_launch();
-}
-
-// Streaming (T = 1): lh_linear_res (intra) + lh_inter_block + lh_qkv_proj_ln of one block as ONE launch (k_qkv_proj_ln<true>).
-extern "C" int lh_stream_mid(const float* xa, const float* hbuf, const void* wlin1_pk, const float* blin1, const void* wgate_pk,
-                             const float* bgate, const void* wlin2_pk, const float* blin2, const float* h0, const float* c0,
-                             float* hN, float* cN, float* xc, const void* wqkv_pk, const float* bqkv, const float* slopes,
-                             const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
-                             const float* lnv_w, const float* lnv_b, void* q, void* kx, void* vx, const int* ring_pos, int B,
-                             lh_stream_t stream) {
-    using namespace lh;
-    if (!xa || !hbuf || !wlin1_pk || !blin1 || !wgate_pk || !bgate || !wlin2_pk || !blin2 || !h0 || !c0 || !hN || !cN || !xc ||
-        !wqkv_pk || !bqkv || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !q || !kx || !vx || B <= 0)
-        return LH_ERR_ARG;
-    if (h0 == hN || c0 == cN || xa == xc) return LH_ERR_ARG;
-    MidArgs m{xa, hbuf, (const _Float16*)wlin1_pk, blin1, (const _Float16*)wgate_pk, bgate, (const _Float16*)wlin2_pk, blin2,
-              h0, c0, hN, cN, xc};
-    hipLaunchKernelGGL((k_qkv_proj_ln<true>), dim3(B < 256 ? B : 256), dim3(256), 0, (hipStream_t)stream, xc,
-                       (const _Float16*)wqkv_pk, bqkv, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, (_Float16*)q,
-                       (_Float16*)kx, (_Float16*)vx, 1, B, ring_pos, m);
+                       (_Float16*)kx, (_Float16*)vx, T, nframes, ring_pos);
     return check_launch();
 }
 

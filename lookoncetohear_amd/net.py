@@ -171,7 +171,6 @@ class Net(nn.Module):
         self.fuse_intra_min_frames = 8192
         self.inter_matvec_max_seqs = 512        # inter LSTM: per-sequence workgroups up to two rounds of CUs (batch <= 5)
         self.stream_intra_max_frames = 128      # up to here one workgroup per (frame, direction) still finds its own CU
-        self.stream_fused_mid = os.environ.get("LOOKONCE_STREAM_MID", "1") != "0"     # Streamer: lh_stream_mid (A/B: 0)
         self._pack_key = None
         self._packed = None
         self._ws: Dict[tuple, dict] = {}
@@ -516,21 +515,13 @@ class Net(nn.Module):
             kx, vx = rings[i]
             lib.call("lh_intra_stream", P(xa), P(bp["intra_s_wih"]), P(bp["intra_s_b"]), P(bp["intra_s_whh"]), P(hbuf),
                      Bn * T, st)
-            if self.stream_fused_mid:
-                # intra Linear + residual, the inter path's one LSTM step and Q/K/V in one launch (three in round 3)
-                lib.call("lh_stream_mid", P(xa), P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(bp["inter_w16"]),
-                         P(bp["inter_b16"]), P(bp["inter_lin_wu"]), P(bp["inter_lin_b"]), P(sin["h"][i]), P(sin["c"][i]),
-                         P(sout["h"][i]), P(sout["c"][i]), P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]),
-                         P(bp["lnq_w"]), P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]),
-                         P(ws["q"]), P(kx), P(vx), P(pos), Bn, st)
-            else:
-                lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), Bn * T * F_,
-                         2 * H_, st)
-                lib.call("lh_inter_block", P(xb), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
-                         P(bp["inter_lin_b"]), P(sin["h"][i]), P(sin["c"][i]), P(sout["h"][i]), P(sout["c"][i]), P(xc), Bn, T, st)
-                lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
-                         P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
-                         P(kx), P(vx), P(pos), Bn, T, st)
+            lib.call("lh_linear_res", P(hbuf), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb), Bn * T * F_,
+                     2 * H_, st)
+            lib.call("lh_inter_block", P(xb), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
+                     P(bp["inter_lin_b"]), P(sin["h"][i]), P(sin["c"][i]), P(sout["h"][i]), P(sout["c"][i]), P(xc), Bn, T, st)
+            lib.call("lh_qkv_proj_ln", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
+                     P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
+                     P(kx), P(vx), P(pos), Bn, T, st)
             lib.call("lh_local_attn", P(ws["q"]), P(kx), P(vx), P(xb), Bn, T, st)
             g = gain if (i == 0 and self.n_blocks > 1) else None
             lib.call("lh_proj_ln_res", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
