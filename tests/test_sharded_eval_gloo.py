@@ -1,5 +1,6 @@
 """CPU, world_size 2, gloo: the N>1 utterance-sharded eval path (shard -> per-rank metric sums -> one all-reduce)
-gives the same aggregate as the single-process run.  The separator is replaced by the CPU oracle on short clips
+gives the same aggregate as the single-process run — through the enrollment branch of the loop (embedding from
+`inputs['enrollments']`, reference src/ts_hear_test.py:132-135; a stand-in embedder here).  The separator is replaced by the CPU oracle on short clips
 (the HIP path cannot run here); what is under test is the sharding / reduction plumbing of lookoncetohear_amd.eval."""
 import os
 import subprocess
@@ -21,7 +22,10 @@ dist.init_process_group(backend="gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 cfg = O.Cfg(**O.TSH_PARAMS); sd = O.synthetic_state_dict(cfg, 0)
 model = lambda m, e: O.forward(cfg, sd, m, e)
-agg, rows = evaluate(model, lambda idx: synth.batch(idx, 1500), n_utts=5, batch_size=2, rank=rank, world=world, dist=dist)
+# enrollment branch of the loop (reference src/ts_hear_test.py:132-135) with a stand-in embedder: unit-norm mean spectrum
+enroll = lambda x: torch.nn.functional.normalize(x.reshape(x.shape[0], -1)[:, :256].abs() + 1e-3, dim=-1)
+agg, rows = evaluate(model, lambda idx: synth.batch(idx, 1500, enroll_n=600), n_utts=5, batch_size=2, rank=rank, world=world,
+                     dist=dist, enroll_model=enroll)
 if rank == 0:
     print("RESULT " + json.dumps(agg))
 dist.destroy_process_group()
@@ -35,7 +39,9 @@ def test_world2_matches_world1(tmp_path):
     assert sorted(shard_indices(5, 0, 2) + shard_indices(5, 1, 2)) == list(range(5))
     cfg = O.Cfg(**O.TSH_PARAMS)
     sd = O.synthetic_state_dict(cfg, 0)
-    ref, rows = evaluate(lambda m, e: O.forward(cfg, sd, m, e), lambda idx: synth.batch(idx, 1500), n_utts=5, batch_size=2)
+    enroll = lambda x: torch.nn.functional.normalize(x.reshape(x.shape[0], -1)[:, :256].abs() + 1e-3, dim=-1)
+    ref, rows = evaluate(lambda m, e: O.forward(cfg, sd, m, e), lambda idx: synth.batch(idx, 1500, enroll_n=600), n_utts=5,
+                         batch_size=2, enroll_model=enroll)
     assert ref["n"] == 5 and len(rows) == 5
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
