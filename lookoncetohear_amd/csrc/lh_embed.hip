@@ -586,6 +586,13 @@ constexpr int ER_RING = 8;                 // position slots
 constexpr int ER_POS = 16 * ER_RP;         // halves per position slot (16 sequences)
 constexpr int ER_NFRAG = 2 * (EKS * 2 + 2) * 2;   // per wave: 2 tiles x (4 slots x 2 k-steps + 2 k-steps of W_hh) x (hi, lo) = 40
 
+#if defined(ER_TRACE)            // timing probe build only (scripts/probe_emb_rec.py): s_memtime stamps of waves 0 and 4 of workgroup 5
+__device__ unsigned long long er_trace_buf[2 * 64 * 8];
+#define ER_STAMP(k) do { if (tr_on && it >= 8 && it < 72) tr[((it - 8) * 8) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ER_STAMP(k) do { } while (0)
+#endif
+
 template <bool INTER>
 __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict__ xs, const _Float16* __restrict__ w_pk,
                                                       const float* __restrict__ bias, _Float16* __restrict__ hs, int nseq,
@@ -597,6 +604,10 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
     const int dir = blockIdx.y, s0 = blockIdx.x * 16;
     const int L = P + EKS - 1;
     const long hrows = (long)nseq * P;
+#if defined(ER_TRACE)
+    const bool tr_on = blockIdx.x == 5 && blockIdx.y == 0 && (tid & 255) == 0;
+    unsigned long long* const tr = er_trace_buf + (tid >> 8) * 512;
+#endif
 
     // resident A fragments
     f16x8 wxh[2][EKS][2], wxl[2][EKS][2], whh[2][2], whl[2][2];
@@ -710,6 +721,7 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
     auto step = [&](int it, f16x8& stg) {
         const int cur = it & 1;
         const bool more = it + 1 < P;                     // (the last step still runs the x half: its result is dropped)
+        ER_STAMP(0);
         f16x8 hh[2], hl[2], xh[2], xl[2];
         {
             const _Float16* base = &himg[cur * ER_POS + frag_off];
@@ -779,6 +791,7 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
         };
         x_group(std::integral_constant<int, 0>{}, std::false_type{});
         __builtin_amdgcn_sched_barrier(0);
+        ER_STAMP(1);
         // issue priority for the MFMAs on the chain (lh_set_tuning key 16): the SIMD's other wave is in its off-chain groups
         // half of the time, and the arbiter otherwise lets those in first (k_inter_xp: -22 % from the same switch)
         if (prio) __builtin_amdgcn_s_setprio(3);
@@ -792,13 +805,17 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
             }
         if (prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        ER_STAMP(2);
         xp_for<7>([&](auto g_) { x_group(std::integral_constant<int, decltype(g_)::value + 1>{}, std::true_type{}); });
+        ER_STAMP(3);
         if (more) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 gxn[j] = f32x4{xm[j][0] + xc[j][0], xm[j][1] + xc[j][1], xm[j][2] + xc[j][2], xm[j][3] + xc[j][3]};
         }
+        ER_STAMP(4);
         __syncthreads();
+        ER_STAMP(5);
     };
     int it = 0;
     for (; it + 1 < P; it += 2) {
@@ -1523,6 +1540,11 @@ extern "C" int lh_emb_axis(const float* x, const void* wih_pk, const float* bih,
     return check_launch();
 }
 
+#if defined(ER_TRACE)
+extern "C" int lh_probe_er_trace_read(unsigned long long* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(lh::er_trace_buf), sizeof(lh::er_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 namespace lh {
 static int g_rec_prio = 0;              // lh_set_tuning key 16: issue priority for k_emb_rec's on-chain MFMAs (0 = off)
 int emb_set(int key, int value) {
