@@ -160,7 +160,7 @@ class Net(nn.Module):
         # memory the kernel stores to directly, one per device, never shared with another Net or a Streamer).
         #   range_check = True / "deferred" (default): the forward stays asynchronous; the word is looked at when the NEXT
         #       forward starts and in `range_status()`, and a set word raises LH_ERR_RANGE there.  (Round 3 ended every
-        #       forward with a host wait: 7.58 -> 7.36 ms per batch-32 step without it, profiles/r04e.)
+        #       forward with a host wait: 7.58 -> 7.36 ms per batch-32 step without it, profiles/r04e_range_check_sync_cost.txt.)
         #   range_check = "sync": wait for the stream at the end of every forward and raise from the forward that
         #       produced the samples (LOOKONCE_RANGE_CHECK=sync); False / LOOKONCE_RANGE_CHECK=0: never look.
         rc = os.environ.get("LOOKONCE_RANGE_CHECK", "1")
@@ -315,6 +315,8 @@ class Net(nn.Module):
         """Waits for the current stream of `device`, then reads and clears this Net's range flag: True when a forward since
         the last look stored zeros in place of non-finite samples.  Call it after the last forward of a loop (a set flag
         otherwise raises at the start of the next forward)."""
+        if device is None and not self._range_flags:
+            return False                                      # no forward has run yet
         dev = torch.device(device) if device is not None else torch.device(next(iter(self._range_flags)))
         flag = self._range_flag(dev)
         if dev.type == "cuda":
