@@ -796,7 +796,8 @@ def main():
             "metric": "frames_per_sec (5 s 16 kHz binaural clips, 625 STFT frames each, offline forward)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 via f16x3 split (3x fp16 MFMA per product, fp32 accumulate; ~22-bit operands)"
+            "dtype": ("f32 via f16x3 split (3x fp16 MFMA per product, fp32 accumulate; ~22-bit operands, un-normalised rows "
+                      "scaled by a power of two before the split: any finite fp32 range)"
                       if net.gemm_mode == "f16x3" else "f32 (exact fp32 MFMA recurrences, split-precision frame kernels)"),
             "data": "synthetic",
             "rtf": elapsed / (total_clips * CLIP_SECONDS),
