@@ -84,7 +84,8 @@ int lh_abi_version(void);
  * lh_deconv_istft (0 = automatic: 256 / B), key 7 = bytes of dynamic LDS added to k_intra_xp launches (timing probe:
  * one workgroup per CU), key 8 = issue priority in k_intra_xp (0 = none, 1 = static priority for the odd wave slot of a SIMD: default, 2 / 3 =
  * every wave raised during the on-chain / off-chain phase of the step), key 9 = issue priority in k_inter_xp (0 = none,
- * 1 / 2 = the LayerNorm / projection waves, 3 = every wave during the on-chain phase: default, 4 = off-chain phase),
+ * 1 / 2 = the LayerNorm / projection waves, 3 = every wave during the on-chain phase: default, 4 = off-chain phase; + 16 = the
+ * two roles on the other four waves: A/B only, 6-8 % slower),
  * key 16 = issue priority for the on-chain MFMAs of the embedder's recurrent kernel k_emb_rec (0 = off: default, 1 = on). */
 int lh_set_tuning(int key, int value);
 

@@ -445,8 +445,15 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     __shared__ __attribute__((aligned(16))) float hf[NS * XP_LSP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Roles: four waves run the output projection and finish rows ("lin"), four normalise and split x ("LN").  The two waves
+    // of a SIMD are w and w + 4, and without a hint the lower-numbered one wins the arbiter; `prio` bit 4 (lh_set_tuning key 9,
+    // + 16) swaps the roles' halves: LN — the heavier on-chain phase in the s_memtime trace — on waves 0..3.
+    const bool role_swap = (prio & 16) != 0;
+    prio &= 15;
+    const bool lin_wave = (wave < 4) != role_swap;
+    const int rw = wave & 3;                      // index inside the role's four waves
     // A/B switch (lh_set_tuning key 9): issue priority for one role — 1 = the LayerNorm waves, 2 = the projection waves
-    if ((prio == 1 && wave >= 4) || (prio == 2 && wave < 4)) __builtin_amdgcn_s_setprio(3);
+    if ((prio == 1 && !lin_wave) || (prio == 2 && lin_wave)) __builtin_amdgcn_s_setprio(3);
 #if defined(XP_TRACE)
     __shared__ unsigned long long tr_all[2 * 128 * 4];
     const bool tr_on = blockIdx.x == 3 && (threadIdx.x & 255) == 0;
@@ -454,7 +461,6 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
 #endif
     const int s0 = blockIdx.x * NS;
     const int g4 = lane >> 4, l15 = lane & 15;
-    const bool lin_wave = wave < 4;
     const int q = tid & 15, rrow = (tid & 255) >> 4;
     // a lane's two cells are ADJACENT units 8w + 2 g4 + m (tile m holds the even / odd units of the wave: weights.py
     // pack_lstm_f16x3_w8), so h leaves as ONE 4-byte LDS store per half instead of two 2-byte stores 8 bytes apart (the 2-byte
@@ -487,10 +493,10 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     if (lin_wave) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            lwh[ks] = *reinterpret_cast<const xp_f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16]);
-            lwl[ks] = *reinterpret_cast<const xp_f16x8*>(&wlin_pk[((wave * 2 + ks) * 64 + lane) * 16 + 8]);
+            lwh[ks] = *reinterpret_cast<const xp_f16x8*>(&wlin_pk[((rw * 2 + ks) * 64 + lane) * 16]);
+            lwl[ks] = *reinterpret_cast<const xp_f16x8*>(&wlin_pk[((rw * 2 + ks) * 64 + lane) * 16 + 8]);
         }
-        if (!accumulate) lbias = blin[wave * 16 + l15];
+        if (!accumulate) lbias = blin[rw * 16 + l15];
     } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) lwh[ks] = lwl[ks] = xp_f16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -506,7 +512,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     const int a_cell = l15 * XP_AP + C + unit0;
     const int a_row = rrow * XP_AP + q * 4;
     const int l_row = rrow * XP_LSP + q * 4;
-    const int l_lin = (g4 * 4) * XP_LSP + wave * 16 + l15;
+    const int l_lin = (g4 * 4) * XP_LSP + rw * 16 + l15;
 
     auto store_split4 = [&](int idx, float a, float b, float c, float d) {
         xp_f16x4 h4, l4;

@@ -112,7 +112,7 @@ def test_previous_fused_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     assert (y - yo).abs().max() < TOL
 
 
-@pytest.mark.parametrize("tune5", [0, 2], ids=["k_inter_xp", "k_lstm_lin8p"])
+@pytest.mark.parametrize("tune5", [0, 2, (0, 19)], ids=["k_inter_xp", "k_lstm_lin8p", "k_inter_xp-roles-swapped"])
 def test_fused_inter_kernels(emu_net, oracle_cfg_sd, tune5):
     """k_inter_xp (lh_recur.hip, the default) and the previous k_lstm_lin8p (lh_set_tuning(5, 2)): B=6 (582 sequences = 37 tiles, last one ragged; above
     the per-sequence mat-vec kernel's batch limit), T=7, carried (h0, c0) in and (hN, cN) out against the oracle."""
@@ -122,11 +122,16 @@ def test_fused_inter_kernels(emu_net, oracle_cfg_sd, tune5):
     d = synth.batch(list(range(20, 20 + B)), 128 * T + 64)
     st = O.random_state(cfg, B, 13)
     yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    tune9 = 3                                              # (default: every wave raised during the on-chain phase)
+    if isinstance(tune5, tuple):                           # key 9 + 16: the projection / LayerNorm roles on the other four waves
+        tune5, tune9 = tune5
     lib.call("lh_set_tuning", 5, tune5)
+    lib.call("lh_set_tuning", 9, tune9)
     try:
         y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
     finally:
         lib.call("lh_set_tuning", 5, 0)
+        lib.call("lh_set_tuning", 9, 3)
     assert (y - yo).abs().max() < TOL
     fo, fm = O.flat_state(so), O.flat_state(s2)
     for k in fo:
