@@ -677,8 +677,8 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
         xh = *reinterpret_cast<const f16x8*>(base);
         xl = *reinterpret_cast<const f16x8*>(base + 64);
     };
-    auto gate_x = [&](int it, f32x4 (&out)[2]) {             // plain form (prologue)
-        f32x4 am[2], ac[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto gate_x = [&](int it, f32x4 (&am)[2], f32x4 (&ac)[2]) {             // plain form (prologue)
+        ac[0] = ac[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         bias_acc(am);
         xp_for<8>([&](auto g_) {
             constexpr int g = decltype(g_)::value, k4 = g >> 1, ks = g & 1;
@@ -691,8 +691,6 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
                 ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wxl[j][k4][ks], xh, ac[j], 0, 0, 0);
             }
         });
-#pragma unroll
-        for (int j = 0; j < 2; ++j) out[j] = f32x4{am[j][0] + ac[j][0], am[j][1] + ac[j][1], am[j][2] + ac[j][2], am[j][3] + ac[j][3]};
     };
 
     // prologue: positions 0..5 into the ring, positions 6 and 7 in flight; h_{-1} = 0
@@ -710,17 +708,22 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
     }
     float creg[2] = {0.f, 0.f};
     __syncthreads();
-    f32x4 gxn[2];
-    gate_x(0, gxn);
+    // Two accumulator sets (hh products | cross terms), alternating by step parity: the x half of step it + 1 is accumulated into
+    // set (it + 1) & 1 during step it, and step it + 1's MFMAs on the chain simply continue in the same registers — no sum, no copy
+    // between the steps (16 vector instructions and 8 registers per step less than summing into a third set)
+    f32x4 gm[2][2], gc[2][2];
+    gate_x(0, gm[0], gc[0]);
 
     // One step, hand-ordered (hipcc's own schedule ran all 60 MFMAs, then the ~75 vector instructions of the two cell
     // updates with the matrix pipe idle, then the barrier: 3300 cycles per step against 2040 of MFMA issue for the two waves
     // of a SIMD).  Order: h fragments + first x group issued -> x group 0 (6 MFMAs, off the chain, while the h reads land)
     // -> the 12 MFMAs on the chain -> x groups 1..7 (42 MFMAs), each MFMA followed by one slice of the cell update and a
     // scheduling fence, the next group's fragments read one group ahead.
-    auto step = [&](int it, f16x8& stg) {
+    auto step = [&](int it, f16x8& stg, auto par_) {
+        constexpr int PAR = decltype(par_)::value;        // it & 1, compile time: selects the accumulator sets
+        f32x4 (&am)[2] = gm[PAR], (&ac)[2] = gc[PAR], (&xm)[2] = gm[PAR ^ 1], (&xc)[2] = gc[PAR ^ 1];
         const int cur = it & 1;
-        const bool more = it + 1 < P;                     // (the last step still runs the x half: its result is dropped)
+        // (the last step still runs an x half — of a clamped window — whose result is dropped)
         ER_STAMP(0);
         f16x8 hh[2], hl[2], xh[2], xl[2];
         {
@@ -732,8 +735,7 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
             }
         }
         x_frag(it + 1, 0, xh[0], xl[0]);
-        f32x4 am[2] = {gxn[0], gxn[1]}, ac[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // on the chain
-        f32x4 xm[2], xc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};                          // x half of step it + 1
+        xc[0] = xc[1] = f32x4{0.f, 0.f, 0.f, 0.f};        // x half of step it + 1 (am / ac: this step's, on the chain)
         bias_acc(xm);
         // cell update of the two units of this lane, cut into 29 slices (lstm_cell_pre's arithmetic, same operation order)
         float a[2][4], r[2][4], g2[2], cc[2], hv[2];
@@ -808,21 +810,16 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
         ER_STAMP(2);
         xp_for<7>([&](auto g_) { x_group(std::integral_constant<int, decltype(g_)::value + 1>{}, std::true_type{}); });
         ER_STAMP(3);
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                gxn[j] = f32x4{xm[j][0] + xc[j][0], xm[j][1] + xc[j][1], xm[j][2] + xc[j][2], xm[j][3] + xc[j][3]};
-        }
         ER_STAMP(4);
         __syncthreads();
         ER_STAMP(5);
     };
     int it = 0;
     for (; it + 1 < P; it += 2) {
-        step(it, stA);
-        step(it + 1, stB);
+        step(it, stA, std::integral_constant<int, 0>{});
+        step(it + 1, stB, std::integral_constant<int, 1>{});
     }
-    if (it < P) step(it, stA);
+    if (it < P) step(it, stA, std::integral_constant<int, 0>{});
     if (!loader) flush_h(P - 1, P & 1);
 }
 
