@@ -743,7 +743,9 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
         auto cell_op = [&](auto k_) {
             constexpr int k = decltype(k_)::value;
             if constexpr (k >= 0 && k < 26) {
-                constexpr int j = k / 13, o = k % 13;
+                // the two cells' slices alternate: a slice's input is two slots old (each slice depends on the cell's previous
+                // one — transcendental latency — so cell 0 then cell 1 made every slot wait for the one before)
+                constexpr int j = k & 1, o = k >> 1;
                 if constexpr (o == 0) { a[j][0] = am[j][0] + ac[j][0]; a[j][1] = am[j][1] + ac[j][1]; }
                 if constexpr (o == 1) { a[j][2] = am[j][2] + ac[j][2]; a[j][3] = am[j][3] + ac[j][3]; }
                 if constexpr (o == 2) { a[j][0] = __builtin_amdgcn_exp2f(a[j][0]); a[j][1] = __builtin_amdgcn_exp2f(a[j][1]); }

@@ -41,3 +41,6 @@ for w in range(2):
     step = t[w, 1:, 0] - t[w, :-1, 0]
     print(f"wave {4 * w}: cycles per step {step.mean():.0f} (min {step.min():.0f}, max {step.max():.0f}); " +
           ", ".join(f"{n} {v:.0f}" for n, v in zip(names, d.mean(0))))
+    if t[w, :, 6].any():          # finer stamps inside the zip: after slot 23 and after slot 35 (of 42)
+        z = np.stack([t[w, :, 6] - t[w, :, 2], t[w, :, 7] - t[w, :, 6], t[w, :, 3] - t[w, :, 7]], 1).mean(0)
+        print(f"         zip: slots 0..23 {z[0]:.0f} ({z[0] / 24:.1f} per slot), 24..35 {z[1]:.0f} ({z[1] / 12:.1f}), 36..41 {z[2]:.0f} ({z[2] / 6:.1f})")
