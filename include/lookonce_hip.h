@@ -38,8 +38,9 @@ enum {
  * stream in lh_qkv_proj_ln and lh_deconv_istft) multiply each row / tile by an exact power of two chosen from its own
  * maximum before the split and undo it after the fp32 accumulation (since ABI 12), so any finite fp32 input whose exact
  * result is finite in fp32 is computed to the same ~22 bits relative to the row maximum — the reference's behaviour
- * (plain fp32, tfgridnet_causal.py:188-283).  What remains is a GUARD for non-finite data: lh_deconv_istft stores 0 (not
- * NaN / inf) for a non-finite output sample and raises a CALLER-OWNED flag:
+ * (plain fp32, tfgridnet_causal.py:188-283).  What remains is a GUARD for non-finite data: lh_deconv_istft raises a
+ * CALLER-OWNED flag for a non-finite output sample and stores it as the caller asks (`keep_nonfinite`, ABI 13: as it is —
+ * the reference's behaviour, the default of the offline host — or as 0 for a listener):
  *   range_flag       two 32-bit words of DEVICE-ACCESSIBLE memory (device memory, or pinned host memory the caller reads
  *                    directly — the streaming host does that and needs no polling launch at all), zero-initialised by the
  *                    caller: [0] = sticky word lh_deconv_istft sets to 1 with a system-scope store (NULL = no reporting),
@@ -251,11 +252,47 @@ int lh_proj_ln_res(const float* merged, const void* w_pk, const float* bias, con
  *   wdec_pk fp16 hi/lo B image [3 ntiles][2 ksteps][64 lanes][16] of deconv.weight as [(kt,kf,o) 36 -> 48] x [64 c];
  *   bdec [4]; wfb_dec fp16 hi/lo B image [12 ntiles][7 ksteps][64 lanes][16] of dec.filterbank._filters^T
  *   [192 samples] x [194 -> 224 rows]   (weights.py pack_linear_f16x3)
- *   wave_out [B][2][128*T];  range_flag: the caller's two-word flag (range contract above) or NULL
+ *   wave_out [B][2][128*T];  range_flag: the caller's two-word flag (range contract above) or NULL;
+ *   keep_nonfinite (ABI 13): what a non-finite output sample is stored as — 1: as it is (inf / NaN reach the caller exactly
+ *   as from the reference's plain-fp32 forward, nothing is hidden; the offline host `Net` passes 1), 0: as 0 (silence, not
+ *   NaN, reaches a listener; the streaming host passes 0).  The flag is raised either way.
  */
 int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out, const float* istft_buf_in,
                     float* istft_buf_out, const void* wdec_pk, const float* bdec, const void* wfb_dec,
-                    float* wave_out, unsigned* range_flag, int B, int T, lh_stream_t stream);
+                    float* wave_out, unsigned* range_flag, int keep_nonfinite, int B, int T, lh_stream_t stream);
+
+/* ---- plain-fp32 reference kernels of the frame stages (gemm_mode "f32all"; lh_ref32.hip) ----------------------------------
+ * The product frame kernels above are split-precision (fp16 hi + lo, ~22 bits) in EVERY arithmetic mode; with these and the
+ * exact fp32-MFMA recurrences (lh_ln_lstm_intra / _inter in LH_GEMM_F32) a forward exists whose every contraction is an
+ * fp32 fmaf chain like the reference's (tfgridnet_causal.py:188-283): the A/B that separates split-precision error from a
+ * kernel bug on a real checkpoint.  Written for obviousness (one thread per output, natural summation order), ~50x slower
+ * than the product path, test / diagnosis only.  Weights are the PyTorch tensors of the state dict as they are (no packed
+ * images); activations channel-last [B][T][97][64] like everywhere else; Q / K / V plain fp32:
+ *   q [4B][T][582], kx [4B][T+49][582], vx [4B][T+49][1552] (rows 0..48 = K_buf / V_buf, copied by the caller).
+ * lh_ref32_stft_conv_in   :229-242   filters = enc.filterbank._filters [194][1][192]; conv_w [64][4][3][3]; spec_scratch
+ *                                    [B][4][T+2][97]
+ * lh_ref32_linear         out[r][n] = (res[r][n] +) act(bias[n] + sum_k in[r][k] w[n][k]); slope = PReLU weight or NULL
+ * lh_ref32_head_ln        :360-376   head split + LayerNorm over (f, d) of columns col0 + h*D + d of `pre` [B][T][97][ncol]
+ *                                    into dst[(b*4+h)][row0 + t][f*D + d]; D = 6 (Q, K) or 16 (V)
+ * lh_ref32_local_attn     :564-581   50 slots, no mask; merged [B][T][4][97][16]
+ * lh_ref32_proj_ln_res    :583-588, 250-251   w [64][64]; rows_scratch, pre_scratch [B*T*97][64]
+ * lh_ref32_deconv_istft   :256-273, net.py:61   deconv_w [64][4][3][3]; filters = dec.filterbank._filters; sx_scratch
+ *                                    [B][2][T+1][194]; non-finite samples are stored as they are (no flag)
+ */
+int lh_ref32_stft_conv_in(const float* x, const float* conv_buf_in, float* conv_buf_out, const float* filters,
+                          const float* conv_w, const float* conv_b, float* spec_scratch, float* out, int B, int T,
+                          int n_samples, lh_stream_t stream);
+int lh_ref32_linear(const float* in, const float* w, const float* bias, const float* slope, const float* res, float* out,
+                    int rows, int K, int N, lh_stream_t stream);
+int lh_ref32_head_ln(const float* pre, int ncol, int col0, int D, const float* ln_w, const float* ln_b, float* dst,
+                     int row0, int rows_per_bh, int B, int T, lh_stream_t stream);
+int lh_ref32_local_attn(const float* q, const float* kx, const float* vx, float* merged, int B, int T, lh_stream_t stream);
+int lh_ref32_proj_ln_res(const float* merged, const float* w, const float* bias, const float* slope, const float* ln_w,
+                         const float* ln_b, const float* y2, const float* gain, float* rows_scratch, float* pre_scratch,
+                         float* out, int B, int T, lh_stream_t stream);
+int lh_ref32_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out, const float* istft_buf_in,
+                          float* istft_buf_out, const float* deconv_w, const float* deconv_b, const float* filters,
+                          float* sx_scratch, float* wave_out, int B, int T, lh_stream_t stream);
 
 /* ---- enrollment embedder (reference src/models/tfgridnet_orig/tfgridnet.py:88-127 + espnet2 TF-GridNet trunk) ----
  * Front end, tfgridnet.py:109-117: x / std(x) (unbiased, over samples and mics), STFT(n_fft 128, hop 64, hann, centred
@@ -269,6 +306,7 @@ int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_pk, const f
                     const float* gn_w, const float* gn_b, double* gn_part, float* z, void* xsplit_next, int B, int T,
                     int n_samples, lh_stream_t stream);
 
+#ifdef LH_LEGACY  /* A/B lab builds only (-DLH_LEGACY): not exported by the product library */
 /* One axis path of an espnet2 GridNetBlock of the embedder (intra: inter = 0, sequences = frames, scan over the 65
  * bins; inter = 1: sequences = bins, scan over time): LayerNorm(C) -> unfold(4) -> BiLSTM(256 -> 64) ->
  * ConvTranspose1d(128 -> 64, 4) -> + residual, as three launches (input GEMM over all windows, recurrence, gather-GEMM).
@@ -280,6 +318,7 @@ int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_pk, const f
 int lh_emb_axis(const float* x, const void* wih_pk, const float* bih, const void* whh_pk, const void* wct_pk,
                 const float* bct, void* xsplit, float* gx, float* hbuf, float* out, int B, int T, int inter,
                 lh_stream_t stream);
+#endif /* LH_LEGACY */
 
 /* The same axis path without the gate pre-activation round trip (round 4): LayerNorm + split -> ONE recurrent kernel that
  * computes the 256-wide input half one step ahead of the dependent chain (weights resident in registers, one workgroup of

@@ -11,7 +11,7 @@ from ctypes import c_int, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _P, _I = c_void_p, c_int
 # name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
@@ -34,9 +34,8 @@ SIGNATURES = {
     "lh_ring_unpack": [_P] * 4 + [_I, _I, _P],
     "lh_ring_advance": [_P, _I, _P],
     "lh_proj_ln_res": [_P] * 9 + [_I, _I, _P],
-    "lh_deconv_istft": [_P] * 10 + [_I, _I, _P],
+    "lh_deconv_istft": [_P] * 10 + [_I, _I, _I, _P],
     "lh_emb_frontend": [_P] * 10 + [_I, _I, _I, _P],
-    "lh_emb_axis": [_P] * 10 + [_I, _I, _I, _P],
     "lh_emb_axis_fused": [_P] * 8 + [_I, _I, _I, _I, _I, _P],
     "lh_emb_attn_block": [_P] * 24 + [_I, _I, _P],
     "lh_emb_head": [_P] * 7 + [_I, _I, _P],
@@ -50,6 +49,17 @@ SIGNATURES = {
     "lh_comm_init": [_P, _I, _I, _P],
     "lh_allreduce_f64": [_P, _P, _I, _P],
     "lh_comm_destroy": [_P],
+    # plain-fp32 reference kernels of the frame stages (gemm_mode "f32all", lh_ref32.hip)
+    "lh_ref32_stft_conv_in": [_P] * 8 + [_I, _I, _I, _P],
+    "lh_ref32_linear": [_P] * 6 + [_I, _I, _I, _P],
+    "lh_ref32_head_ln": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "lh_ref32_local_attn": [_P] * 4 + [_I, _I, _P],
+    "lh_ref32_proj_ln_res": [_P] * 11 + [_I, _I, _P],
+    "lh_ref32_deconv_istft": [_P] * 10 + [_I, _I, _P],
+}
+# entry points of lab / emulator builds only (-DLH_LEGACY, include/lookonce_hip.h `#ifdef LH_LEGACY`): bound when present
+LEGACY_SIGNATURES = {
+    "lh_emb_axis": [_P] * 10 + [_I, _I, _I, _P],
 }
 ERRORS = {1: "LH_ERR_ARG", 2: "LH_ERR_UNSUPPORTED", 3: "LH_ERR_LAUNCH", 4: "LH_ERR_RANGE"}
 
@@ -72,6 +82,11 @@ class Lib:
             fn = getattr(self._dll, name)          # AttributeError here = missing export
             fn.argtypes = argtypes
             fn.restype = c_int
+        for name, argtypes in LEGACY_SIGNATURES.items():      # lab / emulator builds (-DLH_LEGACY) only
+            fn = getattr(self._dll, name, None)
+            if fn is not None:
+                fn.argtypes = argtypes
+                fn.restype = c_int
         v = self._dll.lh_abi_version()
         if v != ABI_VERSION:
             raise RuntimeError(f"{path}: ABI version {v}, expected {ABI_VERSION}")
@@ -88,14 +103,42 @@ class Lib:
 def device_of(t):
     """Context manager: make `t`'s GPU the current HIP device around raw C-ABI launches (they go to the CURRENT device,
     and the reference eval driver builds `cuda:N` tensors without torch.cuda.set_device, src/ts_hear_test.py:175).
-    No-op for host tensors (only the emulator test hook passes those)."""
-    import contextlib
+    """
     import torch
-    return torch.cuda.device(t.device) if t.is_cuda else contextlib.nullcontext()
+    return torch.cuda.device(t.device)
 
 
 _hip_lib = None
 _selftested = set()
+
+
+class HipHost:
+    """Device plumbing of the host classes (`Net`, `EmbedTFGridNet`, `BinauralRenderer`): where the C-ABI library comes
+    from, which HIP stream the launches go to, which device is current around them, and where a caller-owned flag word
+    lives.  ROCm device tensors only — there is no CPU path.  (tests/hipemu subclasses the hosts and overrides exactly
+    these four methods to drive the same host code over the emulated library; the product classes carry no test hook.)"""
+    _host_name = "this module"
+
+    def _lib(self, t) -> "Lib":
+        if not t.is_cuda:
+            raise RuntimeError(f"lookoncetohear_amd.{self._host_name} runs on an MI355X (ROCm device tensors); there is no "
+                               "CPU path. Move the module and its inputs to cuda.")
+        lib = load()
+        import torch
+        selftest_device(lib, t.device.index if t.device.index is not None else torch.cuda.current_device())
+        return lib
+
+    def _stream(self, device) -> int:
+        import torch
+        return torch.cuda.current_stream(device).cuda_stream
+
+    def _device_ctx(self, t):
+        return device_of(t)
+
+    def _flag_words(self, device):
+        """Two zeroed 32-bit words in pinned host memory: device-accessible, and readable by the host without a copy."""
+        import torch
+        return torch.zeros(2, dtype=torch.int32).pin_memory()
 
 
 def selftest_device(lib: "Lib", device_index: int) -> None:

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_recur.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_render_fft.hip", "lh_stream.hip", "lh_comm.hip"]
+SOURCES = ["lh_frontend.hip", "lh_lstm.hip", "lh_recur.hip", "lh_pointwise.hip", "lh_attn.hip", "lh_backend.hip", "lh_metrics.hip", "lh_embed.hip", "lh_render.hip", "lh_render_fft.hip", "lh_stream.hip", "lh_comm.hip", "lh_ref32.hip"]
 LIB = os.path.join(PKG, "_lookonce_hip.so")
 ARCH = "gfx950"
 # -fno-slp-vectorize for EVERY file: hipcc's SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_add_f32 /
@@ -58,9 +58,12 @@ def _llvm_bin() -> str:
             cands.append(os.path.join(os.environ[var], "llvm", "bin"))
     cands.append("/opt/rocm/lib/llvm/bin")
     for c in cands:
-        if os.path.exists(os.path.join(c, "llvm-objdump")):
+        # BOTH tools the guard runs: llvm-objdump (disassembly) and llvm-mc (self-test probe) — ADVICE r4: a directory with
+        # only the first passed here and guard_selftest then died with a bare FileNotFoundError after the whole compile
+        if all(os.path.exists(os.path.join(c, t)) for t in ("llvm-objdump", "llvm-mc")):
             return c
-    raise RuntimeError("ISA guard of build.py: llvm-objdump not found (looked in " + ", ".join(cands) + "); set ROCM_PATH")
+    raise RuntimeError("ISA guard of build.py: llvm-objdump + llvm-mc not found together (looked in " + ", ".join(cands) +
+                       "); set ROCM_PATH")
 
 
 _GUARD_SELFTEST = {}
@@ -78,11 +81,11 @@ def guard_selftest() -> None:
         src, obj = os.path.join(td, "g.s"), os.path.join(td, "g.o")
         open(src, "w").write("v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]\nv_pk_add_f32 v[0:1], v[2:3], v[4:5]\n"
                              "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0]\n")
-        r = subprocess.run([os.path.join(llvm, "llvm-mc"), "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", src, "-o", obj],
+        r = subprocess.run([os.path.join(llvm, "llvm-mc"), "-arch=amdgcn", f"-mcpu={ARCH}", "-filetype=obj", src, "-o", obj],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("ISA guard self-test: llvm-mc could not assemble the probe: " + r.stderr[-300:])
-        d = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", obj], capture_output=True, text=True).stdout
+        d = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", f"--mcpu={ARCH}", obj], capture_output=True, text=True).stdout
     lines = [ln for ln in d.splitlines() if "v_pk_" in ln]
     flags = [is_unsafe_packed_fp32(ln) for ln in lines]
     if flags != [True, False, True]:
@@ -115,7 +118,7 @@ def unsafe_packed_fp32(lib_path: str):
             for k, off in enumerate(hits):
                 co = os.path.join(td, f"co{k}.o")
                 open(co, "wb").write(raw[off:])
-                r = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True)
+                r = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", f"--mcpu={ARCH}", co], capture_output=True, text=True)
                 if "v_mfma" in r.stdout or "v_pk_" in r.stdout:
                     text += r.stdout
     bad = [line.strip() for line in text.splitlines() if is_unsafe_packed_fp32(line)]
@@ -137,6 +140,7 @@ def build_hip(force: bool = False, verbose: bool = True, extra_flags=(), out: st
                                                        os.path.join(os.path.dirname(PKG), "include", "lookonce_hip.h")]
     if not force and _newer(out, deps):
         return out
+    guard_selftest()                         # before the compile: a toolchain the guard cannot read fails in a second, not after minutes
     objdir = os.path.join(PKG, "build" if out == LIB else "build_" + os.path.basename(out).replace(".so", ""))
     os.makedirs(objdir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", *NO_SLP, *extra_flags]
@@ -158,7 +162,6 @@ def build_hip(force: bool = False, verbose: bool = True, extra_flags=(), out: st
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    guard_selftest()
     bad, n_packed, seen = unsafe_packed_fp32(tmp_out)
     if not seen or bad:
         rejected = out + ".rejected"

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
                                                         float* __restrict__ ibuf_out, const _Float16* __restrict__ wd_pk,
                                                         const float* __restrict__ bd, const _Float16* __restrict__ wfb_pk,
                                                         float* __restrict__ wave_out, unsigned* __restrict__ range_flag,
-                                                        int B, int T, int runs_per_b) {
+                                                        int keep_nonfinite, int B, int T, int runs_per_b) {
     // Two input frames per loop iteration (half the barriers; at one frame the loop was ~80 % stall): two A images, and
     // a partial-product ring of 4 frames (2 being written while the gather still reads the 2 before them).
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * FR_A];                 // A images of two input frames
@@ -431,10 +431,11 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
             const int n = i % HOP, s = (i / HOP) % NSRC, jt = i / (HOP * NSRC);
             float v = frs[jt + 1][s][n];
             if (n < NFFT - HOP) v += frs[jt][s][n + HOP];
-            // inf / NaN: the fp16 split overflowed upstream (or the input held inf / NaN).  The sample is stored as 0 —
-            // silence, not NaN, reaches a listener — and the CALLER's flag word is raised (range contract, lookonce_hip.h)
+            // inf / NaN (the input or the state held inf / NaN, or a true fp32 overflow): the CALLER's flag word is raised
+            // (range contract, lookonce_hip.h) and the sample is stored as the caller asked — as it is (the reference's
+            // behaviour: NaN out, nothing hidden; the offline host) or as 0 (silence, not NaN, reaches a listener; streaming)
             const bool nf = (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;
-            wave_out[((long)b * NSRC + s) * L + (long)(t0 + jt) * HOP + n] = nf ? 0.f : v;
+            wave_out[((long)b * NSRC + s) * L + (long)(t0 + jt) * HOP + n] = (nf && !keep_nonfinite) ? 0.f : v;
             bad |= nf;
         }
         // sticky until lh_range_status / lh_range_flag_copy fetch it.  A plain store (every writer writes 1), system scope: the
@@ -470,8 +471,8 @@ extern "C" int lh_probe_be_trace_read(unsigned long long* host_dst) {
 
 extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_buf_out,
                                const float* istft_buf_in, float* istft_buf_out, const void* wdec_pk,
-                               const float* bdec, const void* wfb_dec, float* wave_out, unsigned* range_flag, int B,
-                               int T, lh_stream_t stream) {
+                               const float* bdec, const void* wfb_dec, float* wave_out, unsigned* range_flag,
+                               int keep_nonfinite, int B, int T, lh_stream_t stream) {
     using namespace lh;
     if (!y || !deconv_buf_in || !deconv_buf_out || !istft_buf_in || !istft_buf_out || !wdec_pk || !bdec || !wfb_dec ||
         !wave_out || B <= 0 || T <= 0)
@@ -484,7 +485,7 @@ extern "C" int lh_deconv_istft(const float* y, const float* deconv_buf_in, float
     const int n_runs = B * runs_per_b;
     hipLaunchKernelGGL(k_deconv_istft, dim3(n_runs < 256 ? n_runs : 256), dim3(BE_NT), 0, (hipStream_t)stream, y,
                        deconv_buf_in, deconv_buf_out, istft_buf_in, istft_buf_out, (const _Float16*)wdec_pk, bdec,
-                       (const _Float16*)wfb_dec, wave_out, range_flag, B, T, runs_per_b);
+                       (const _Float16*)wfb_dec, wave_out, range_flag, keep_nonfinite, B, T, runs_per_b);
     return check_launch();
 }
 

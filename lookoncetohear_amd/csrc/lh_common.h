@@ -186,12 +186,40 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // 2^-11 |v| — seen as 6e-5 errors of whole LSTM outputs against 3e-7 (round 3; which pattern the compiler picks changes
 // with every flag, the SLP build of rounds 1-2 happened to be consistent).  The empty asm makes the operand opaque: the
 // product is rounded to fp32 once and both conversions start from that register.
+// Round 5: on gfx950 the split is written in the three instructions it needs (the compiler's form was four per value:
+// v_cvt_f16_f32, v_cvt_f32_f16, v_sub_f32 + its half of a v_cvt_pk_f16_f32 that converts `hi` a second time for the store):
+//   hi = v_cvt_f16_f32(v);  d = v_fma_mix_f32(hi as f16, -1.0, v) = v - hi, exact;  lo = v_cvt_f16_f32(d)
+// and `hi` is one register by construction, so no opaque-operand trick is needed.  Same bits as before (both conversions
+// round to nearest even, the difference is exact in fp32).  The host build (tests/hipemu) keeps the portable form.
 __device__ __forceinline__ void split_hl(float v, _Float16& hi, _Float16& lo) {
 #if defined(__AMDGCN__)
-    asm("" : "+v"(v));
-#endif
+    float d;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(hi) : "v"(v));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi), "v"(v));
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(lo) : "v"(d));
+#else
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
+#endif
+}
+// Two values at once, results PACKED (element 0 in the low half): v_cvt_pk_f16_f32 (gfx950) + two v_fma_mix_f32 reading
+// the halves of the packed register + v_cvt_pk_f16_f32 = 2 instructions per value, packing included (the single form
+// plus the compiler's packs: 3; the compiler's own: 4).  Bit-identical to two split_hl.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float v0, float v1, f16x2_t& hi, f16x2_t& lo) {
+#if defined(__AMDGCN__)
+    float d0, d1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "v"(v1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+#else
+    _Float16 h0, l0, h1, l1;
+    split_hl(v0, h0, l0);
+    split_hl(v1, h1, l1);
+    hi = f16x2_t{h0, h1};
+    lo = f16x2_t{l0, l1};
+#endif
 }
 
 // "The value of v is decided HERE": an empty volatile asm that claims to rewrite the registers.  Arithmetic on a global

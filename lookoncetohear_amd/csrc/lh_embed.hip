@@ -311,6 +311,8 @@ __global__ void __launch_bounds__(256) k_emb_lnsplit(const float* __restrict__ x
         ln_split_store(*reinterpret_cast<const float4*>(&x[r * C + q * 4]), xh, xl, r * C + q * 4, true);
 }
 
+#if defined(LH_LEGACY)   // round-1 axis path (k_emb_gx -> k_emb_lstm -> k_emb_convt_res behind lh_emb_axis): A/B lab + emulator
+                         // builds only; the product library launches k_emb_rec / k_emb_convt2 (lh_emb_axis_fused)
 // Gx[s*P + p][chunk*128 ..] = W_ih' [xhat(s, p) | xhat(s, p+1) | xhat(s, p+2) | xhat(s, p+3)] + b'
 // One tile = 64 consecutive windows of ONE sequence: its 67 position rows are staged once (16-byte copies of the
 // pre-split images, no conversion) and the unfold is just a row offset in the A-fragment address (k-step ks covers
@@ -558,6 +560,8 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt_res(const float* __restric
         }
     }
 }
+
+#endif  // LH_LEGACY
 
 // ---------------------------------------------------------------------------------------------------------------
 // Round 4: the axis path without the gate pre-activation round trip.  k_emb_gx wrote Gx = [rows x 512] fp32 (10.2 GB per
@@ -1502,6 +1506,7 @@ extern "C" int lh_emb_frontend(const float* x, float* inv_std, const float* wfb_
     return check_launch();
 }
 
+#if defined(LH_LEGACY)
 // One axis path of a GridNetBlock: inter = 0 along frequency (sequences = frames), 1 along time (sequences = bins).
 //   x, out [B][T][65][64] (must not alias); wih_pk fp16 hi/lo image [32 ntiles][8 ksteps][64][16] of the folded,
 //   column-permuted input weights of both directions; bih [512]; whh_pk [2][4][4][2][64][16]; wct_pk [4][16][64][16]
@@ -1538,6 +1543,8 @@ extern "C" int lh_emb_axis(const float* x, const void* wih_pk, const float* bih,
     }
     return check_launch();
 }
+
+#endif  // LH_LEGACY
 
 #if defined(ER_TRACE)
 extern "C" int lh_probe_er_trace_read(unsigned long long* host_dst) {

@@ -98,14 +98,10 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
                 const int e = tid + FE_NTH * i;
                 const int m = e / (FE_NJ * 48), j = (e / 48) % FE_NJ, c4 = e % 48;
                 const float v[4] = {stg[i].x * tsc, stg[i].y * tsc, stg[i].z * tsc, stg[i].w * tsc};
-                f16x4 h4, l4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    _Float16 h, l;
-                    split_hl(v[q], h, l);
-                    h4[q] = h;
-                    l4[q] = l;
-                }
+                f16x2_t h01, l01, h23, l23;
+                split_pair(v[0], v[1], h01, l01);
+                split_pair(v[2], v[3], h23, l23);
+                const f16x4 h4 = f16x4{h01[0], h01[1], h23[0], h23[1]}, l4 = f16x4{l01[0], l01[1], l23[0], l23[1]};
                 const int idx = (m * FE_NJ + j) * FE_AP + c4 * 4;
                 *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
                 *reinterpret_cast<f16x4*>(&alo[idx]) = l4;
@@ -273,7 +269,7 @@ extern "C" int lh_embed_proj_ln(const float* emb, const float* w, const float* b
     return check_launch();
 }
 
-extern "C" int lh_abi_version(void) { return 12; }
+extern "C" int lh_abi_version(void) { return 13; }
 
 extern "C" int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unused, int lstm_hidden,
                                int n_heads, int attn_window, int n_srcs, int spk_emb_dim) {

@@ -391,6 +391,9 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__
     }
 }
 
+#if defined(LH_LEGACY)   // A/B lab + emulator builds only (python -m lookoncetohear_amd.build --variant legacy -DLH_LEGACY):
+                         // the fused intra kernel of round 2, superseded by k_intra_xp (lh_recur.hip); the product library
+                         // contains only kernels a product configuration can launch
 // ------------------------------------------------------------------------------------------------------
 // Recurrence with the following Linear + residual fused in ("lin" kernels): instead of writing the hidden states
 // to HBM for a separate pointwise kernel, every step also multiplies h_{t-1} by the wave's 16 columns of the
@@ -712,6 +715,8 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
     store_rows(nstep - 1, nstep & 1, rr);
 }
 
+#endif  // LH_LEGACY
+
 // ------------------------------------------------------------------------------------------------------
 // Eight-wave, software-pipelined fused recurrence for the inter pass (k_lstm_lin8p): 625 dependent steps and, at batch 32,
 // only 194 sixteen-sequence tiles for 256 CUs, i.e. one workgroup per CU.  Same tile (16 sequences, all steps) and LDS
@@ -979,6 +984,7 @@ __global__ void __launch_bounds__(512, 1) k_lstm_lin8p(const float* __restrict__
     }
 }
 
+#if defined(LH_LEGACY)
 static int g_dephase = 1;          // lh_set_tuning(3, 0) switches the slot-parity issue priority off (A/B runs)
 template <int MT>
 static int launch_lstm_lin(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
@@ -994,6 +1000,7 @@ static int launch_lstm_lin(const float* x, const void* w_pk, const float* b_sum,
     return check_launch();
 }
 
+#endif  // LH_LEGACY
 template <int MT>
 static int launch_lstm_h3(const float* x, const float* lnw, const float* lnb, const void* w_pk, const float* b_sum,
                           const float* h0, const float* c0, float* hN, float* cN, float* h_out, int nseq, int nstep,
@@ -1053,8 +1060,12 @@ extern "C" int lh_set_tuning(int key, int value) {
     if (key >= 7 && key < 16) return lh::xp_set(key, value);      // lh_recur.hip switches
     if (key == 16) return lh::emb_set(key, value);                // lh_embed.hip: k_emb_rec issue priority
     if (key < 0 || key >= 8) return LH_ERR_ARG;
-    lh::g_tune[key] = value;
+#if defined(LH_LEGACY)
     if (key == 3) lh::g_dephase = value;
+#else
+    if (key == 2 && value == 2) return LH_ERR_UNSUPPORTED;       // k_ln_lstm_lin: lab builds only (-DLH_LEGACY)
+#endif
+    lh::g_tune[key] = value;
     return LH_OK;
 }
 
@@ -1131,11 +1142,15 @@ extern "C" int lh_intra_block(const float* x, const void* w_pk, const float* b_s
     // sequence = frame (b,t), step = frequency bin; forward launch then reverse launch (accumulating)
     int rc = LH_OK;
     for (int dir = 0; dir < 2 && rc == LH_OK; ++dir)
-        if (g_tune[2] != 2)                       // software-pipelined, hand-ordered step (lh_recur.hip); 2 = previous kernel (A/B)
+#if defined(LH_LEGACY)
+        if (g_tune[2] == 2)                       // the previous fused kernel (A/B lab builds only)
+            rc = launch_lstm_lin<1>(x, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, nullptr, nullptr,
+                                    nullptr, nullptr, out, n_frames, NF, 1, NF, 0, 1, dir, dir, st);
+        else
+#endif
+            // software-pipelined, hand-ordered step (lh_recur.hip)
             rc = launch_intra_xp(x, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, out, n_frames,
                                  NF, 1, NF, 0, 1, dir, dir, st);
-        else rc = launch_lstm_lin<1>(x, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, nullptr, nullptr,
-                                nullptr, nullptr, out, n_frames, NF, 1, NF, 0, 1, dir, dir, st);
     return rc;
 }
 
@@ -1148,7 +1163,9 @@ extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_s
     // sequence s = b*97 + f; step = frame t; row(s, t) = (b*T + t)*97 + f.  Eight-wave tiles (k_lstm_lin8p): the pass is a
     // 625-step dependent chain, two waves per SIMD cover each other's latencies
     const int nseq = B * NF;
-    if (g_tune[5] != 2 && T >= 2)                 // hand-ordered step with per-phase issue priority (lh_recur.hip); 2 = previous kernel (A/B)
+    // T >= 2: the hand-ordered step with per-phase issue priority (k_inter_xp, lh_recur.hip: its software pipeline needs a
+    // second step); a single frame (streaming chunks) runs k_lstm_lin8p below; lh_set_tuning(5, 2) forces it (A/B)
+    if (g_tune[5] != 2 && T >= 2)
         return launch_inter_xp(x, w_pk, b_sum, wlin_pk, blin, h0, c0, hN, cN, out, nseq, T, NF, T * NF, 1, NF,
                                (hipStream_t)stream);
     hipLaunchKernelGGL(k_lstm_lin8p, dim3((nseq + 15) / 16), dim3(512), 0, (hipStream_t)stream, x, (const _Float16*)w_pk,

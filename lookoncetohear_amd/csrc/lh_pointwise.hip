@@ -151,12 +151,11 @@ struct HeadLN {
             const float bv[8] = {b[k][0].x, b[k][0].y, b[k][0].z, b[k][0].w, b[k][1].x, b[k][1].y, b[k][1].z, b[k][1].w};
             f16x8 h8, l8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float y = x[k][e] * rstd * wv[e] + bv[e];
-                _Float16 h, l;
-                split_hl(y, h, l);
-                h8[e] = h;
-                l8[e] = l;
+            for (int e = 0; e < 8; e += 2) {
+                f16x2_t h2, l2;
+                split_pair(x[k][e] * rstd * wv[e] + bv[e], x[k][e + 1] * rstd * wv[e + 1] + bv[e + 1], h2, l2);
+                h8[e] = h2[0]; h8[e + 1] = h2[1];
+                l8[e] = l2[0]; l8[e + 1] = l2[1];
             }
             f16x8 o0 = h8, o1 = l8;
             if (VLAYOUT) {

@@ -167,15 +167,10 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
     auto load_x = [&](int it) -> float4 { return *reinterpret_cast<const float4*>(xb + step_pos(it) * step_bytes + voff); };
     auto load_base = [&](int it) -> float4 { return *reinterpret_cast<const float4*>(bsrc + step_pos(it) * step_bytes + voff); };
     auto store_split4 = [&](int idx, float a, float b, float c, float d) {
-        xp_f16x4 h4, l4;
-        const float v[4] = {a, b, c, d};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            _Float16 th, tl;
-            split_hl(v[i], th, tl);
-            h4[i] = th;
-            l4[i] = tl;
-        }
+        f16x2_t h01, l01, h23, l23;
+        split_pair(a, b, h01, l01);
+        split_pair(c, d, h23, l23);
+        const xp_f16x4 h4 = xp_f16x4{h01[0], h01[1], h23[0], h23[1]}, l4 = xp_f16x4{l01[0], l01[1], l23[0], l23[1]};
         *reinterpret_cast<xp_f16x4*>(&ahi[idx]) = h4;
         *reinterpret_cast<xp_f16x4*>(&alo[idx]) = l4;
     };
@@ -280,9 +275,9 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
 #endif
             [&] { y.x = v.x * rstd; y.y = v.y * rstd; },
             [&] { y.z = v.z * rstd; y.w = v.w * rstd; },
-            [&] { _Float16 a_, b_; split_hl(y.x, a_, b_); h4[0] = a_; l4[0] = b_; },
-            [&] { _Float16 a_, b_; split_hl(y.y, a_, b_); h4[1] = a_; l4[1] = b_; },
-            [&] { _Float16 a_, b_, c_, d_; split_hl(y.z, a_, b_); split_hl(y.w, c_, d_); h4[2] = a_; l4[2] = b_; h4[3] = c_; l4[3] = d_; },
+            [&] { f16x2_t a_, b_; split_pair(y.x, y.y, a_, b_); h4[0] = a_[0]; h4[1] = a_[1]; l4[0] = b_[0]; l4[1] = b_[1]; },
+            [&] { },
+            [&] { f16x2_t a_, b_; split_pair(y.z, y.w, a_, b_); h4[2] = a_[0]; h4[3] = a_[1]; l4[2] = b_[0]; l4[3] = b_[1]; },
             [&] {
                 *reinterpret_cast<xp_f16x4*>(&ahi[cur * NS * XP_AP + a_row]) = h4;
                 *reinterpret_cast<xp_f16x4*>(&alo[cur * NS * XP_AP + a_row]) = l4;
@@ -515,15 +510,10 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     const int l_lin = (g4 * 4) * XP_LSP + rw * 16 + l15;
 
     auto store_split4 = [&](int idx, float a, float b, float c, float d) {
-        xp_f16x4 h4, l4;
-        const float v[4] = {a, b, c, d};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            _Float16 th, tl;
-            split_hl(v[i], th, tl);
-            h4[i] = th;
-            l4[i] = tl;
-        }
+        f16x2_t h01, l01, h23, l23;
+        split_pair(a, b, h01, l01);
+        split_pair(c, d, h23, l23);
+        const xp_f16x4 h4 = xp_f16x4{h01[0], h01[1], h23[0], h23[1]}, l4 = xp_f16x4{l01[0], l01[1], l23[0], l23[1]};
         *reinterpret_cast<xp_f16x4*>(&ahi[idx]) = h4;
         *reinterpret_cast<xp_f16x4*>(&alo[idx]) = l4;
     };
@@ -639,9 +629,9 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
                 [&] { y.x = v.x * rstd; y.y = v.y * rstd; },
                 [&] { y.z = v.z * rstd; y.w = v.w * rstd; },
                 [&] { carry = load_row(xb, it + 2 + XP_PF); },      // behind the last use of v: the fetch can land in v's registers
-                [&] { _Float16 a_, b_; split_hl(y.x, a_, b_); h4[0] = a_; l4[0] = b_; },
-                [&] { _Float16 a_, b_; split_hl(y.y, a_, b_); h4[1] = a_; l4[1] = b_; },
-                [&] { _Float16 a_, b_, c_, d_; split_hl(y.z, a_, b_); split_hl(y.w, c_, d_); h4[2] = a_; l4[2] = b_; h4[3] = c_; l4[3] = d_; },
+                [&] { f16x2_t a_, b_; split_pair(y.x, y.y, a_, b_); h4[0] = a_[0]; h4[1] = a_[1]; l4[0] = b_[0]; l4[1] = b_[1]; },
+                [&] { },
+                [&] { f16x2_t a_, b_; split_pair(y.z, y.w, a_, b_); h4[2] = a_[0]; h4[3] = a_[1]; l4[2] = b_[0]; l4[3] = b_[1]; },
                 [&] {
                     *reinterpret_cast<xp_f16x4*>(&ahi[cur * NS * XP_AP + a_row]) = h4;
                     *reinterpret_cast<xp_f16x4*>(&alo[cur * NS * XP_AP + a_row]) = l4;
@@ -688,15 +678,14 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
         };
         auto cG = [&](auto m_) { constexpr int m = decltype(m_)::value; tc[m] = 1.0f + __builtin_amdgcn_exp2f(creg[m]); };
         auto cH = [&](auto m_) { constexpr int m = decltype(m_)::value; tc[m] = __builtin_amdgcn_rcpf(tc[m]); };
-        _Float16 th2[2], tl2[2];
         auto cI = [&](auto m_) {
             constexpr int m = decltype(m_)::value;
             hreg[m] = acc[m][3] * __builtin_fmaf(2.0f, tc[m], -1.0f);
-            split_hl(hreg[m], th2[m], tl2[m]);
-            if constexpr (m == 1) {                // units unit0, unit0 + 1: one packed store per half
-                typedef _Float16 xp_f16x2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<xp_f16x2*>(&ahi[nxt * NS * XP_AP + a_cell]) = xp_f16x2{th2[0], th2[1]};
-                *reinterpret_cast<xp_f16x2*>(&alo[nxt * NS * XP_AP + a_cell]) = xp_f16x2{tl2[0], tl2[1]};
+            if constexpr (m == 1) {                // units unit0, unit0 + 1: one pair split, one packed store per half
+                f16x2_t th2, tl2;
+                split_pair(hreg[0], hreg[1], th2, tl2);
+                *reinterpret_cast<f16x2_t*>(&ahi[nxt * NS * XP_AP + a_cell]) = th2;
+                *reinterpret_cast<f16x2_t*>(&alo[nxt * NS * XP_AP + a_cell]) = tl2;
             }
         };
         using M0 = std::integral_constant<int, 0>;

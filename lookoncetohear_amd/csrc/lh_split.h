@@ -26,15 +26,10 @@ __device__ __forceinline__ int a_index(int row, int k) {
 
 template <int RP>
 __device__ __forceinline__ void store_split4(_Float16* ahi, _Float16* alo, int row, int k0, float4 v) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    f16x4 h4, l4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        _Float16 h, l;
-        split_hl(x[i], h, l);
-        h4[i] = h;
-        l4[i] = l;
-    }
+    f16x2_t h01, l01, h23, l23;
+    split_pair(v.x, v.y, h01, l01);
+    split_pair(v.z, v.w, h23, l23);
+    const f16x4 h4 = f16x4{h01[0], h01[1], h23[0], h23[1]}, l4 = f16x4{l01[0], l01[1], l23[0], l23[1]};
     const int idx = a_index<RP>(row, k0);
     *reinterpret_cast<f16x4*>(&ahi[idx]) = h4;
     *reinterpret_cast<f16x4*>(&alo[idx]) = l4;

@@ -61,7 +61,9 @@ def stft_rows(n_fft: int) -> torch.Tensor:
     return torch.from_numpy(np.concatenate([np.cos(ang), -np.sin(ang)], axis=1) * win[:, None]).float()
 
 
-class EmbedTFGridNet(nn.Module):
+class EmbedTFGridNet(_cabi.HipHost, nn.Module):
+    _host_name = "EmbedTFGridNet"
+
     def __init__(self, embed_dim, num_ch, n_fft, stride, num_blocks):
         super().__init__()
         if (embed_dim, num_ch, n_fft, stride) != (256, 2, 128, 64):
@@ -77,25 +79,16 @@ class EmbedTFGridNet(nn.Module):
         self._pack_key = None
         self._packed = None
         # axis path: k_emb_rec (input GEMM inside the recurrence, round 4) or the round-1 three-kernel form with the gate
-        # pre-activations through HBM (LOOKONCE_EMB_FUSED=0; A/B runs)
+        # pre-activations through HBM (LOOKONCE_EMB_FUSED=0; A/B runs against a -DLH_LEGACY lab build only: the product
+        # library does not contain it and the call fails loudly)
         import os
         self.fused_axis = os.environ.get("LOOKONCE_EMB_FUSED", "1") != "0"
         self.n_streams = int(os.environ.get("LOOKONCE_EMB_STREAMS", "2"))
         self._side = None
-        self._lib_override = None          # TEST HOOK ONLY (tests/hipemu)
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: (C-ABI call, start event, end event) per launch
 
     # ------------------------------------------------------------------------------------------------
-    def _lib(self, t):
-        if self._lib_override is not None:
-            return self._lib_override
-        if not t.is_cuda:
-            raise RuntimeError("lookoncetohear_amd.EmbedTFGridNet runs on an MI355X (ROCm device tensors); there is no CPU path")
-        lib = _cabi.load()
-        _cabi.selftest_device(lib, t.device.index if t.device.index is not None else torch.cuda.current_device())
-        return lib
-
     def _weights(self, device) -> dict:
         tensors = list(self.parameters())
         key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
@@ -113,13 +106,15 @@ class EmbedTFGridNet(nn.Module):
         is 520 workgroups of one-per-CU on 256 CUs: a third round with 8 of them) is filled by the other half's kernels."""
         ns = self.n_streams
         ns = min(ns, input.shape[0] // 16)
-        if ns > 1 and input.is_cuda and self._prof is None and self._debug_taps is None:
+        if ns > 1 and self._multi_stream(input) and self._prof is None and self._debug_taps is None:
             dev = input.device
             with torch.no_grad():
                 self._weights(dev)                                      # packed once, on the caller's stream
             cur = torch.cuda.current_stream(dev)
-            if self._side is None or self._side[0] != dev:
-                self._side = (dev, [torch.cuda.Stream(device=dev) for _ in range(ns - 1)])
+            if self._side is None or self._side[0] != dev or len(self._side[1]) < ns - 1:
+                # sized for the configured stream count, not for this call's batch-capped `ns` (ADVICE r4: a first call at
+                # B = 32 gave one side stream and a later B = 64 call with n_streams = 4 indexed past it)
+                self._side = (dev, [torch.cuda.Stream(device=dev) for _ in range(max(ns, self.n_streams) - 1)])
             parts = list(input.chunk(ns))
             outs = [None] * len(parts)
             for i in range(1, len(parts)):
@@ -133,6 +128,9 @@ class EmbedTFGridNet(nn.Module):
                 outs[i].record_stream(cur)
             return torch.cat(outs, 0)
         return self._forward_one(input)
+
+    def _multi_stream(self, input) -> bool:
+        return True
 
     def _forward_one(self, input):
         lib = self._lib(input)
@@ -149,13 +147,13 @@ class EmbedTFGridNet(nn.Module):
         if self.training and torch.is_grad_enabled():
             raise RuntimeError("lookoncetohear_amd.EmbedTFGridNet is an inference-only drop-in (no autograd): call .eval() "
                                "and/or run under torch.no_grad()")
-        with torch.no_grad(), _cabi.device_of(x):
+        with torch.no_grad(), self._device_ctx(x):
             pk = self._weights(dev)
-            st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
+            st = self._stream(dev)
             P = lambda t: t.data_ptr()
             e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
             taps = self._debug_taps
-            prof = self._prof if x.is_cuda else None
+            prof = self._prof
             if prof is not None:
                 lib_ = lib
 

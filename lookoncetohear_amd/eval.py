@@ -20,11 +20,16 @@ def shard_indices(n_utts: int, rank: int, world: int) -> List[int]:
 
 
 def evaluate(model: Callable, data_fn: Callable[[List[int]], dict], n_utts: int, batch_size: int = 4,
-             rank: int = 0, world: int = 1, device="cpu", dist=None, enroll_model: Optional[Callable] = None):
+             rank: int = 0, world: int = 1, device="cpu", dist=None, enroll_model: Optional[Callable] = None,
+             range_status: Optional[Callable[[], bool]] = None):
     """Returns (mean si_snr_i, mean output_sisnr, mean embedding_sim, n) over ALL ranks, plus this rank's rows.
 
     `model(mixture [B,2,N], embedding [B,1,256]) -> [B,2,N]` is the separator (`Net.forward`);
-    `data_fn(indices)` returns the dict of reference dataset fields (mixture, target, embedding_gt[, enrollments]).
+    `data_fn(indices)` returns the dict of reference dataset fields (mixture, target, embedding_gt[, enrollments]);
+    `range_status`: the separator's `Net.range_status` when `model` is a wrapper around it (a closure has none; a `Net` or its
+    bound `forward` is found by itself).  Non-finite data cannot go unnoticed either way: the offline forward hands inf / NaN
+    through like the reference (`keep_nonfinite`), so the metric sums of such a batch are NaN; the check below runs AFTER
+    the collective and on every rank, so no rank is left waiting in it.
     """
     mine = shard_indices(n_utts, rank, world)
     total = torch.zeros(4, dtype=torch.float64, device=device)
@@ -53,13 +58,18 @@ def evaluate(model: Callable, data_fn: Callable[[List[int]], dict], n_utts: int,
                 o, i, c = per_utterance(outputs, mixture, target, embedding[:, 0], emb_gt[:, 0])
             rows += [dict(idx=k, output_sisnr=float(a), si_snr_i=float(b), embedding_sim=float(e))
                      for k, a, b, e in zip(idx, o.tolist(), i.tolist(), c.tolist())]
-    # range guard (include/lookonce_hip.h): a Net checks its flag when the NEXT forward starts; after the last batch ask it
-    net = getattr(model, "__self__", model)                  # a bound method (net.forward) or the module itself
-    if callable(getattr(net, "range_status", None)) and getattr(net, "_range_flags", None):
-        if any(net.range_status(dev_key) for dev_key in list(net._range_flags)):
-            raise RuntimeError("LH_ERR_RANGE: the last batch produced non-finite samples (stored as 0): inf / NaN in the input")
+    # range guard (include/lookonce_hip.h): a Net looks at its flag when the NEXT forward starts; after the last batch ask it
+    if range_status is None:
+        net = getattr(model, "__self__", model)              # a bound method (net.forward) or the module itself
+        range_status = getattr(net, "range_status", None)
+    bad = bool(range_status()) if callable(range_status) else False
+    if bad:
+        total[:3] = float("nan")                             # the other ranks learn it from the all-reduced sums
     if dist is not None and world > 1:
         dist.all_reduce(total)                               # sum over ranks, 32 bytes
+    if bad or not bool(torch.isfinite(total).all()):
+        raise RuntimeError("LH_ERR_RANGE: a batch of this evaluation produced non-finite samples (inf / NaN in the input)"
+                           + ("" if bad else " on another rank, or its metrics are not finite"))
     n = max(float(total[3].item()), 1.0)
     return dict(si_snr_i=float(total[0].item()) / n, output_sisnr=float(total[1].item()) / n,
                 embedding_sim=float(total[2].item()) / n, n=int(total[3].item())), rows

@@ -36,14 +36,14 @@ def metric_sums(outputs, mixture, target, embedding, embedding_gt) -> torch.Tens
     return torch.stack([i.double().sum(), o.double().sum(), c.double().sum(), n])
 
 
-def metric_sums_device(outputs, mixture, target, embedding, embedding_gt, lib=None):
+def metric_sums_device(outputs, mixture, target, embedding, embedding_gt, host=None):
     """Same quantities through the HIP kernels of lh_metrics.hip (fp64 moments, one pass over the waveforms).
-    Returns (sums [4] fp64 on device, rows [B,3] fp32 = output_sisnr, si_snr_i, embedding_sim)."""
+    Returns (sums [4] fp64 on device, rows [B,3] fp32 = output_sisnr, si_snr_i, embedding_sim).  `host`: the
+    `_cabi.HipHost` whose library / stream plumbing to use (default: the product library on the tensors' GPU)."""
     from . import _cabi
-    if lib is None:
-        if not outputs.is_cuda:
-            raise RuntimeError("metric_sums_device needs ROCm device tensors (use metric_sums for host tensors)")
-        lib = _cabi.load()
+    if host is None:
+        host = type("MetricHost", (_cabi.HipHost,), {"_host_name": "metric_sums_device"})()
+    lib = host._lib(outputs)
     B, _, n = outputs.shape
     dev = outputs.device
     c32 = lambda t: t.contiguous().float()
@@ -52,8 +52,8 @@ def metric_sums_device(outputs, mixture, target, embedding, embedding_gt, lib=No
     scratch = torch.empty(B * 2 * 16 * 8 + B * 3, dtype=torch.float64, device=dev)
     rows = torch.empty(B, 3, dtype=torch.float32, device=dev)
     sums = torch.empty(4, dtype=torch.float64, device=dev)
-    st = torch.cuda.current_stream(dev).cuda_stream if outputs.is_cuda else 0
-    with _cabi.device_of(o):
+    st = host._stream(dev)
+    with host._device_ctx(o):
         lib.call("lh_metric_sums", o.data_ptr(), t.data_ptr(), m.data_ptr(), e.data_ptr(), g.data_ptr(),
                  scratch.data_ptr(), rows.data_ptr(), sums.data_ptr(), B, n, e.shape[1], st)
     return sums, rows

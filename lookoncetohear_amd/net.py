@@ -44,9 +44,6 @@ def mod_pad(x: torch.Tensor, chunk_size: int, pad: Tuple[int, int]):
     return x, mod
 
 
-_device_of = _cabi.device_of
-
-
 def stft_filterbank(n_fft: int, hop: int) -> torch.Tensor:
     """Analysis/synthesis filterbank buffer `[n_fft + 2, 1, n_fft]` (asteroid-filterbanks STFTFB as called at
     reference tfgridnet_causal.py:131-135): sqrt-periodic-Hann windowed real-DFT rows, 97 cosine rows then 97
@@ -119,7 +116,9 @@ class _TFGridNetParams(nn.Module):
         self.deconv = nn.ConvTranspose2d(emb_dim, n_srcs * 2, (3, 3), padding=(2, 1))
 
 
-class Net(nn.Module):
+class Net(_cabi.HipHost, nn.Module):
+    _host_name = "Net"
+
     def __init__(self, stft_chunk_size=160, stft_pad_size=120, embed_dim=256,
                  num_ch=2, D=64, B=6, I=1, J=1, L=0, H=128,
                  use_attn=False, lookahead=True, local_atten_len=100,
@@ -152,12 +151,16 @@ class Net(nn.Module):
         # contraction arithmetic of the two RECURRENCES: "f16x3" = split-precision fp16 MFMA (hi/lo operands, ~22 mantissa
         # bits, ~5x the fp32-MFMA rate), "f32rec" = exact fp32 MFMA in the intra / inter LSTMs (the name says what it
         # covers: the frame kernels — STFT / conv, Q/K/V, attention, projection, deconv / iSTFT — are split-precision in
-        # every mode; "f32" is accepted as the old spelling).  LOOKONCE_GEMM overrides.
+        # every mode); "f32all" = additionally the frame kernels on plain-fp32 reference kernels (lh_ref32.hip: slow,
+        # test-only — the all-fp32 run that separates "split-precision error" from "kernel bug" on a real checkpoint).
+        # LOOKONCE_GEMM overrides.
         self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
         # range guard of the split-precision kernels (include/lookonce_hip.h): the frame kernels scale every row / tile by
         # a power of two before they split it, so any finite input is in range; non-finite output samples (inf / NaN in
-        # the input, a true fp32 overflow) are stored as 0 and raise THIS Net's flag word (`_range_flag`: pinned host
-        # memory the kernel stores to directly, one per device, never shared with another Net or a Streamer).
+        # the input, a true fp32 overflow) reach the caller AS THEY ARE, like from the reference's plain-fp32 forward
+        # (`keep_nonfinite`, ABI 13: nothing is hidden even when nobody looks at the flag — a `Streamer` stores 0 instead,
+        # silence for a listener) and raise THIS Net's flag word (`_range_flag`: pinned host memory the kernel stores to
+        # directly, one per device, never shared with another Net or a Streamer).
         #   range_check = True / "deferred" (default): the forward stays asynchronous; the word is looked at when the NEXT
         #       forward starts and in `range_status()`, and a set word raises LH_ERR_RANGE there.  (Round 3 ended every
         #       forward with a host wait: 7.58 -> 7.36 ms per batch-32 step without it, profiles/r04e_range_check_sync_cost.txt.)
@@ -176,7 +179,6 @@ class Net(nn.Module):
         self._ws: Dict[tuple, dict] = {}
         self._zeros: Dict[tuple, dict] = {}
         self._blob = None                  # (device, packed tree) when built by `from_packed`
-        self._lib_override = None          # TEST HOOK ONLY (tests/hipemu): never set on the product path
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: list of (kernel tag, start event, end event) per launch
         self._prof_only: Optional[set] = None
@@ -232,16 +234,6 @@ class Net(nn.Module):
     # ------------------------------------------------------------------------------------------------
     # host-side plumbing
     # ------------------------------------------------------------------------------------------------
-    def _lib(self, t: torch.Tensor) -> _cabi.Lib:
-        if self._lib_override is not None:
-            return self._lib_override
-        if not t.is_cuda:
-            raise RuntimeError("lookoncetohear_amd.Net runs on an MI355X (ROCm device tensors); there is no CPU "
-                               "path. Move the module and its inputs to cuda.")
-        lib = _cabi.load()
-        _cabi.selftest_device(lib, t.device.index if t.device.index is not None else torch.cuda.current_device())
-        return lib
-
     @classmethod
     def from_packed(cls, path: str, device) -> "Net":
         """A separator whose weights come ONLY from a packed blob (`checkpoint.export_packed`, format in
@@ -302,13 +294,21 @@ class Net(nn.Module):
             self._ws[key] = ws
         return ws
 
+    @staticmethod
+    def _dev_key(device) -> str:
+        """'cuda' / torch.device('cuda') and 'cuda:N' of the current device are ONE key (`range_status('cuda')`
+        must find the flag the forward keyed by `x.device` = 'cuda:0')."""
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        return str(dev)
+
     def _range_flag(self, device) -> torch.Tensor:
         """This Net's two-word range flag for `device` (include/lookonce_hip.h: [0] sticky, [1] unused here): pinned host
-        memory on the GPU path — device-accessible, and readable by the host without a copy or a launch."""
-        key = str(device)
+        memory — device-accessible, and readable by the host without a copy or a launch."""
+        key = self._dev_key(device)
         if key not in self._range_flags:
-            t = torch.zeros(2, dtype=torch.int32)
-            self._range_flags[key] = t.pin_memory() if torch.device(device).type == "cuda" else t
+            self._range_flags[key] = self._flag_words(torch.device(key))
         return self._range_flags[key]
 
     def range_status(self, device=None) -> bool:
@@ -317,16 +317,18 @@ class Net(nn.Module):
         otherwise raises at the start of the next forward)."""
         if device is None and not self._range_flags:
             return False                                      # no forward has run yet
-        dev = torch.device(device) if device is not None else torch.device(next(iter(self._range_flags)))
+        dev = torch.device(self._dev_key(device)) if device is not None else torch.device(next(iter(self._range_flags)))
         flag = self._range_flag(dev)
-        if dev.type == "cuda":
-            torch.cuda.current_stream(dev).synchronize()
+        self._sync(dev)
         bad = int(flag[0]) != 0
         if bad:
             flag.zero_()
         return bad
 
-    _RANGE_MSG = ("LH_ERR_RANGE: {} produced non-finite samples (stored as 0). The frame kernels scale every row by a power of "
+    def _sync(self, dev):
+        torch.cuda.current_stream(dev).synchronize()
+
+    _RANGE_MSG = ("LH_ERR_RANGE: {} produced non-finite samples. The frame kernels scale every row by a power of "
                   "two before the fp16 hi + lo split, so this means inf / NaN in the input or the state, or an activation "
                   "beyond the fp32 range itself (include/lookonce_hip.h, range contract).")
 
@@ -343,6 +345,8 @@ class Net(nn.Module):
         if self.training and torch.is_grad_enabled():
             raise RuntimeError("lookoncetohear_amd.Net is an inference-only drop-in (forward kernels, no autograd): call "
                                ".eval() and/or run under torch.no_grad(); training stays on the reference model")
+        if self.gemm_mode == "f32all":
+            return self._separate_ref32(x, embed, state, want_state)
         lib = self._lib(x)
         dev = x.device
         if self.range_check and int(self._range_flag(dev)[0]) != 0:       # deferred look at the previous forwards' flag: a host read
@@ -364,16 +368,16 @@ class Net(nn.Module):
         hist = self.local_atten_len - 1
         # raw launches go to the CURRENT HIP device: make it the tensors' device (the reference eval driver builds
         # `cuda:N` tensors without torch.cuda.set_device, src/ts_hear_test.py:175)
-        with torch.no_grad(), _device_of(x):
+        with torch.no_grad(), self._device_ctx(x):
             pk = self._weights(dev)
             ws = self._workspace(Bn, T, dev)
-            st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
+            st = self._stream(dev)
             P = lambda t: t.data_ptr()
             new = lambda t: torch.empty_like(t, dtype=torch.float32)
             c32 = lambda t: t.contiguous().float()
             taps = self._debug_taps
             xa, xb, xc, hbuf = ws["xa"], ws["xb"], ws["xc"], ws["hbuf"]
-            prof = self._prof if x.is_cuda else None
+            prof = self._prof
             only = self._prof_only                   # bench.py: restrict the event pairs to these C-ABI calls
 
             class _Timed:                       # HIP events on the launch stream around each C-ABI call
@@ -398,8 +402,8 @@ class Net(nn.Module):
                 taps["Z0"], taps["G"] = xa.clone(), ws["gain"].clone()
 
             rows = Bn * T * F_
-            if self.gemm_mode not in ("f32rec", "f32", "f16x3"):
-                raise ValueError(f"gemm_mode must be 'f16x3' or 'f32rec', got {self.gemm_mode!r}")
+            if self.gemm_mode not in ("f32rec", "f32all", "f16x3"):
+                raise ValueError(f"gemm_mode must be 'f16x3', 'f32rec' or 'f32all', got {self.gemm_mode!r}")
             mode = 1 if self.gemm_mode == "f16x3" else 0
             wkey, bkey = ("_w16", "_b16") if mode else ("_w", "_b")
             for i in range(self.n_blocks):
@@ -474,12 +478,105 @@ class Net(nn.Module):
             y = torch.empty(Bn, self.n_srcs, hop * T, device=dev, dtype=torch.float32)
             flag = self._range_flag(dev)
             lib.call("lh_deconv_istft", P(xa), P(dec_in), P(dec_out), P(ist_in), P(ist_out), P(pk["deconv_w"]),
-                     P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), P(flag), Bn, T, st)
+                     P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y), P(flag), 1, Bn, T, st)
             if want_state:
                 state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
-            if self.range_check == "sync" and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if self.range_check == "sync" and not self._capturing():
                 if self.range_status(dev):
                     raise RuntimeError(self._RANGE_MSG.format("this forward"))
+        return y, (state if want_state else None)
+
+    def _capturing(self) -> bool:
+        return torch.cuda.is_current_stream_capturing()
+
+    def _separate_ref32(self, x: torch.Tensor, embed: torch.Tensor, state: Optional[dict], want_state: bool = True):
+        """`gemm_mode = "f32all"`: the same forward with EVERY contraction in plain fp32 — the exact fp32-MFMA recurrences
+        (`lh_ln_lstm_intra / _inter`, LH_GEMM_F32) between the plain-fp32 reference kernels of lh_ref32.hip for the frame
+        stages (weights straight from the state dict, Q / K / V as fp32 rows).  Slow (~50x), allocation-happy, test /
+        diagnosis only: the in-tree A/B that tells split-precision error from a kernel bug (reference arithmetic:
+        tfgridnet_causal.py:188-283 is fp32 end to end)."""
+        if self._blob is not None:
+            raise RuntimeError("gemm_mode='f32all' reads the parameter tree; a `from_packed` Net has none")
+        lib = self._lib(x)
+        dev = x.device
+        hop, nfft = self.stft_chunk_size, self.nfft
+        assert x.dim() == 3 and x.shape[1] == self.num_ch, "input must be [B, num_ch, N]"
+        Bn, _, n = x.shape
+        if state is None:
+            state = self.init_buffers(Bn, dev)
+        T = (n - nfft) // hop + 1
+        if T < 1:
+            raise ValueError(f"need at least {nfft} samples, got {n}")
+        ns = (T - 1) * hop + nfft
+        x = x[..., :ns].contiguous().float()
+        embed = embed.contiguous().float()
+        F_, C_, nh, H_ = self.n_freqs, self.emb_dim, self.n_head, self.hidden
+        hist = self.local_atten_len - 1
+        rows = Bn * T * F_
+        with torch.no_grad(), self._device_ctx(x):
+            pk = self._weights(dev)                    # only the fp32-MFMA LSTM images and the speaker-gain tensors
+            sd = {k: v.detach().float().contiguous() for k, v in self.tfgridnet.state_dict().items()}
+            st = self._stream(dev)
+            P = lambda t: t.data_ptr()
+            e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+            c32 = lambda t: t.contiguous().float()
+            xa, xb, xc, hbuf = e(Bn, T, F_, C_), e(Bn, T, F_, C_), e(Bn, T, F_, C_), e(rows, 2 * H_)
+            gain_raw, gain = e(Bn, F_ * C_), e(Bn, F_, C_)
+            conv_in = c32(state["conv_buf"]); conv_out = torch.empty_like(conv_in)
+            spec_s, sx_s = e(Bn, 2 * self.num_ch, T + 2, F_), e(Bn, self.n_srcs, T + 1, 2 * F_)   # scratch: named, so they outlive the calls
+            lib.call("lh_ref32_stft_conv_in", P(x), P(conv_in), P(conv_out), P(sd["enc.filterbank._filters"]),
+                     P(sd["conv.0.weight"]), P(sd["conv.0.bias"]), P(spec_s), P(xa), Bn, T, ns, st)
+            lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]), P(pk["emb_ln_b"]),
+                     P(gain_raw), P(gain), Bn, st)                                   # plain fp32 in every mode
+            taps = self._debug_taps
+            if taps is not None:
+                taps["Z0"], taps["G"] = xa.clone(), gain.clone()
+            pre, rows_s, pre_s = e(rows, 112), e(rows, C_), e(rows, C_)
+            q = e(Bn * nh, T, self.E * F_)
+            for i in range(self.n_blocks):
+                bp, bs, g = pk["blocks"][i], state["gridnet_bufs"][f"buf{i}"], f"blocks.{i}."
+                h0, c0 = c32(bs["h0"]), c32(bs["c0"])
+                hN, cN = torch.empty_like(h0), torch.empty_like(c0)
+                lib.call("lh_ln_lstm_intra", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra_w"]), P(bp["intra_b"]),
+                         P(hbuf), Bn * T, 0, st)
+                lib.call("lh_ref32_linear", P(hbuf), P(sd[g + "intra_linear.weight"]), P(sd[g + "intra_linear.bias"]), None,
+                         P(xa), P(xb), rows, 2 * H_, C_, st)
+                lib.call("lh_ln_lstm_inter", P(xb), P(bp["inter_ln_w"]), P(bp["inter_ln_b"]), P(bp["inter_w"]), P(bp["inter_b"]),
+                         P(h0), P(c0), P(hN), P(cN), P(hbuf), Bn, T, 0, st)
+                lib.call("lh_ref32_linear", P(hbuf), P(sd[g + "inter_linear.weight"]), P(sd[g + "inter_linear.bias"]), None,
+                         P(xb), P(xc), rows, H_, C_, st)
+                # Q | K | V: Linear + PReLU (one launch per projection: each has its own slope), head split + LayerNorm
+                kx, vx = e(Bn * nh, T + hist, self.E * F_), e(Bn * nh, T + hist, self.V_dim * F_)
+                kx[:, :hist] = bs["K_buf"].float()
+                vx[:, :hist] = bs["V_buf"].float()
+                for nm, D, dst, row0, rpb in (("Q", self.E, q, 0, T), ("K", self.E, kx, hist, T + hist),
+                                              ("V", self.V_dim, vx, hist, T + hist)):
+                    a = g + f"attn_conv_{nm}."
+                    ncol = nh * D
+                    lib.call("lh_ref32_linear", P(xc), P(sd[a + "0.weight"]), P(sd[a + "0.bias"]), P(sd[a + "1.weight"]), None,
+                             P(pre), rows, C_, ncol, st)
+                    lib.call("lh_ref32_head_ln", P(pre), ncol, 0, D, P(sd[a + "3.norm.weight"]), P(sd[a + "3.norm.bias"]),
+                             P(dst), row0, rpb, Bn, T, st)
+                lib.call("lh_ref32_local_attn", P(q), P(kx), P(vx), P(xb), Bn, T, st)
+                a = g + "attn_concat_proj."
+                gn = gain if (i == 0 and self.n_blocks > 1) else None
+                lib.call("lh_ref32_proj_ln_res", P(xb), P(sd[a + "0.weight"]), P(sd[a + "0.bias"]), P(sd[a + "1.weight"]),
+                         P(sd[a + "3.norm.weight"]), P(sd[a + "3.norm.bias"]), P(xc), P(gn) if gn is not None else None,
+                         P(rows_s), P(pre_s), P(xa), Bn, T, st)
+                if want_state:
+                    bs["h0"], bs["c0"] = hN, cN
+                    bs["K_buf"], bs["V_buf"] = kx[:, T:T + hist].clone(), vx[:, T:T + hist].clone()
+                if taps is not None:
+                    taps[f"blocks.{i}.Y2"], taps[f"blocks.{i}.Q"] = xc.clone(), q.clone()
+                    taps[f"blocks.{i}.K"], taps[f"blocks.{i}.V"] = kx[:, hist:].clone(), vx[:, hist:].clone()
+                    taps[f"blocks.{i}.out"] = xa.clone()
+            dec_in, ist_in = c32(state["deconv_buf"]), c32(state["istft_buf"])
+            dec_out, ist_out = torch.empty_like(dec_in), torch.empty_like(ist_in)
+            y = e(Bn, self.n_srcs, hop * T)
+            lib.call("lh_ref32_deconv_istft", P(xa), P(dec_in), P(dec_out), P(ist_in), P(ist_out), P(sd["deconv.weight"]),
+                     P(sd["deconv.bias"]), P(sd["dec.filterbank._filters"]), P(sx_s), P(y), Bn, T, st)
+            if want_state:
+                state["conv_buf"], state["deconv_buf"], state["istft_buf"] = conv_out, dec_out, ist_out
         return y, (state if want_state else None)
 
     # ------------------------------------------------------------------------------------------------
@@ -489,9 +586,9 @@ class Net(nn.Module):
         """gain[b][f][c] = LayerNorm(Linear(embed)) (reference tfgridnet_causal.py:247-248) into preallocated tensors."""
         lib = self._lib(embed)
         pk = self._weights(embed.device)
-        st = torch.cuda.current_stream(embed.device).cuda_stream if embed.is_cuda else 0
+        st = self._stream(embed.device)
         P = lambda t: t.data_ptr()
-        with _device_of(embed):
+        with self._device_ctx(embed):
             lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]), P(pk["emb_ln_b"]),
                      P(gain_raw), P(gain), embed.shape[0], st)
 
@@ -507,7 +604,7 @@ class Net(nn.Module):
         T = (n - nfft) // hop + 1
         assert T == 1 and n == nfft, "the streaming path takes chunks of stft_chunk_size + stft_pad_size samples"
         F_, H_ = self.n_freqs, self.hidden
-        st = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
+        st = self._stream(dev)
         P = lambda t: t.data_ptr()
         xa, xb, xc, hbuf = ws["xa"], ws["xb"], ws["xc"], ws["hbuf"]
         lib.call("lh_stft_conv_in", P(x), P(sin["conv_buf"]), P(sout["conv_buf"]), P(pk["wfb_t"]), P(pk["conv_w"]),
@@ -530,7 +627,7 @@ class Net(nn.Module):
                      P(bp["proj_ln_w"]), P(bp["proj_ln_b"]), P(xc), P(g) if g is not None else None, P(xa), Bn, T, st)
         lib.call("lh_deconv_istft", P(xa), P(sin["deconv_buf"]), P(sout["deconv_buf"]), P(sin["istft_buf"]),
                  P(sout["istft_buf"]), P(pk["deconv_w"]), P(pk["deconv_b"]), P(pk["wfb_dec"]), P(y),
-                 P(flag) if flag is not None else None, Bn, T, st)
+                 P(flag) if flag is not None else None, 0, Bn, T, st)
 
 
 
@@ -579,16 +676,14 @@ class Streamer:
         # to it directly in the rare chunk that needs it and `step` just reads the word — no exchange kernel, no copy, no
         # extra launches in the chunk loop (round 3 polled with a kernel + copy every 64th chunk: +0.15 ms on that chunk,
         # which was the p99 of the latency distribution).
-        self.range_flag = torch.zeros(2, dtype=torch.int32)
-        if dev.type == "cuda":
-            self.range_flag = self.range_flag.pin_memory()
+        self.range_flag = net._flag_words(dev)
         self.parity = 0
         self.graphs = None
         self.graph = None
         # strong references: the captured graphs bake in pointers into the packed weights and the T=1 workspace.
         # `Net._workspace` evicts its cache after a few shapes and `Net._weights` re-packs after any parameter change;
         # holding the objects here keeps the memory alive, and `step` refuses to replay once the weights were re-packed.
-        with torch.no_grad(), _device_of(self.chunk):
+        with torch.no_grad(), net._device_ctx(self.chunk):
             self._pk = net._weights(dev)
             self._pack_key = net._pack_key
             self._n_steps = 0
@@ -597,7 +692,7 @@ class Streamer:
             self._vpos = 0
             self._ws = net._workspace(B, 1, dev)
             net._ws.pop((B, 1, str(dev)), None)          # private to this streamer from now on
-        if use_graph and dev.type == "cuda":
+        if use_graph:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -614,12 +709,12 @@ class Streamer:
             self.reset()
 
     def _body(self, k: int):
-        with _device_of(self.chunk):
+        with self.net._device_ctx(self.chunk):
             self.net._stream_chunk(self.chunk, self.gain, self.sets[k], self.sets[k ^ 1], self.rings, self.pos, self.out,
                                    self._pk, self._ws, self.range_flag)
             # ring slot counter, kept in [0, window): an ever-growing int32 would go negative after 2^31 chunks and C's
             # `%` would then index before the ring.  One 1-thread kernel (two torch elementwise launches cost 9 us of the chunk)
-            st = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+            st = self.net._stream(self.device)
             self.net._lib(self.pos).call("lh_ring_advance", self.pos.data_ptr(), self.net.local_atten_len, st)
 
     def reset(self):

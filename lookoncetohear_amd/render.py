@@ -16,16 +16,8 @@ import torch
 from . import _cabi
 
 
-class BinauralRenderer:
-    def __init__(self):
-        self._lib_override = None          # TEST HOOK ONLY (tests/hipemu)
-
-    def _lib(self, t):
-        if self._lib_override is not None:
-            return self._lib_override
-        if not t.is_cuda:
-            raise RuntimeError("lookoncetohear_amd.BinauralRenderer runs on an MI355X (ROCm device tensors); there is no CPU path")
-        return _cabi.load()
+class BinauralRenderer(_cabi.HipHost):
+    _host_name = "BinauralRenderer"
 
     def convolve(self, src: torch.Tensor, rir: torch.Tensor) -> torch.Tensor:
         """`_convolve`, batched: src [R, N] mono rows, rir [R, 2, Lh] -> [R, 2, N] (`convolve(...)[:len(src)]` per ear)."""
@@ -54,9 +46,9 @@ class BinauralRenderer:
         events = torch.empty(B, S1, 2, N, device=dev)
         mixture, target = torch.empty(B, 2, N, device=dev), torch.empty(B, 2, N, device=dev)
         peak = torch.empty(B, dtype=torch.int32, device=dev)
-        st = torch.cuda.current_stream(dev).cuda_stream if srcs.is_cuda else 0
+        st = self._stream(dev)
         P = lambda t: t.data_ptr()
-        with _cabi.device_of(srcs):
+        with self._device_ctx(srcs):
             lib.call("lh_render_binaural", P(srcs), P(rirs), P(gains), P(tgt_idx), P(events), P(peak), P(mixture),
                      P(target), B, S1, N, Lh, st)
         return mixture, target, peak.view(torch.float32), events

@@ -47,8 +47,8 @@ class Dims:
         self.lookahead = p["lookahead"]
 
 
-def init_state(d: Dims, B: int, dtype=torch.float32):
-    z = lambda *s: torch.zeros(*s, dtype=dtype)
+def init_state(d: Dims, B: int, dtype=torch.float32, device=None):
+    z = lambda *s: torch.zeros(*s, dtype=dtype, device=device)
     bufs = {f"buf{i}": dict(K_buf=z(B * d.nh, d.win - 1, d.E * d.F), V_buf=z(B * d.nh, d.win - 1, d.Vd * d.F),
                             c0=z(1, B * d.F, d.H), h0=z(1, B * d.F, d.H)) for i in range(d.nblk)}
     return dict(conv_buf=z(B, 2 * d.M, 2, d.F), deconv_buf=z(B, d.C, 2, d.F), istft_buf=z(B, d.S, 2 * d.F, 1),
@@ -129,7 +129,7 @@ def tfgridnet(d: Dims, sd, x, emb, state):
     """TFGridNet.forward (tfgridnet_causal.py:188-283): x [B, M, N'] -> ([B, S, n], state)."""
     p = "tfgridnet."
     if state is None:
-        state = init_state(d, x.shape[0], x.dtype)
+        state = init_state(d, x.shape[0], x.dtype, x.device)
     shp = x.shape
     b = F.conv1d(x.reshape(-1, 1, shp[-1]), sd[p + "enc.filterbank._filters"], stride=d.hop)
     b = b.view(*shp[:-1], b.shape[-2], b.shape[-1])

@@ -65,5 +65,21 @@ profile)            # rocprofv3 kernel stats + PMC passes (separate runs) of the
     python $R/scripts/make_pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv 32 $R/gpurun_out/pmc_traffic.json $R/gpurun_out/pmc_sq.csv $R/gpurun_out/pmc_sq2.csv
     cd $R
     head -40 gpurun_out/kernel_stats.csv; head -60 gpurun_out/pmc_traffic.json ;;
+profile_embed)      # the same evidence set for BASELINE configs[4]: kernel stats + FETCH / WRITE / sq / sq2 passes
+    cd /tmp && export TMPDIR=/tmp       # of `bench.py --mode embed`; merges an `embed` section into gpurun_out/pmc_traffic.json
+    P="python $R/bench.py --mode embed --steps 3 --warmup 1 --no-cpu-baseline"
+    timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/eprof_stats -o r1 -- $P > $R/gpurun_out/eprof_stats.log 2>&1; echo "rocprof rc=$?"
+    python $R/scripts/rocpd_summary.py /tmp/eprof_stats/r1_results.db $R/gpurun_out/embed_kernel_stats.csv
+    for C in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/eprof_$C -o r1 -- $P > $R/gpurun_out/eprof_$C.log 2>&1; echo "rocprof $C rc=$?"
+        python $R/scripts/rocpd_summary.py /tmp/eprof_$C/r1_results.db $R/gpurun_out/embed_pmc_$C.csv --pmc
+    done
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/eprof_sq -o r1 -- $P > $R/gpurun_out/eprof_sq.log 2>&1; echo "rocprof sq rc=$?"
+    python $R/scripts/rocpd_summary.py /tmp/eprof_sq/r1_results.db $R/gpurun_out/embed_pmc_sq.csv --pmc
+    timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM -d /tmp/eprof_sq2 -o r1 -- $P > $R/gpurun_out/eprof_sq2.log 2>&1; echo "rocprof sq2 rc=$?"
+    python $R/scripts/rocpd_summary.py /tmp/eprof_sq2/r1_results.db $R/gpurun_out/embed_pmc_sq2.csv --pmc
+    [ -f $R/gpurun_out/pmc_traffic.json ] || cp $R/profiles/pmc_traffic.json $R/gpurun_out/pmc_traffic.json
+    python $R/scripts/make_pmc_traffic_embed.py $R/gpurun_out/embed_kernel_stats.csv $R/gpurun_out/embed_pmc_FETCH_SIZE.csv $R/gpurun_out/embed_pmc_WRITE_SIZE.csv 64 5 $R/gpurun_out/pmc_traffic.json $R/gpurun_out/embed_pmc_sq.csv $R/gpurun_out/embed_pmc_sq2.csv
+    cd $R; head -24 gpurun_out/embed_kernel_stats.csv ;;
 *)  echo "unknown task $task"; exit 2 ;;
 esac

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "lookonce_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef LH_LEGACY.*?#endif", "", src, flags=re.S)       # lab-build entry points: not in the product library
     out = {}
     for m in re.finditer(r"\bint\s+(lh_\w+)\s*\(([^)]*)\)\s*;", src):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
@@ -40,6 +41,11 @@ def test_hip_library_builds_loads_and_exports():
     lib = _cabi.Lib(build_hip())
     for name in _header_functions():
         assert lib.raw(name) is not None
+    # superseded kernels are not in the product library (they build with -DLH_LEGACY for the A/B lab
+    # and the emulator): their entry point is absent and their tuning switch is refused
+    import ctypes
+    assert not hasattr(ctypes.CDLL(lib.path), "lh_emb_axis")
+    assert lib.raw("lh_set_tuning")(2, 2) == 2 and lib.raw("lh_set_tuning")(2, 0) == 0
     assert lib.raw("lh_abi_version")() == _cabi.ABI_VERSION
     assert lib.raw("lh_check_config")(192, 128, 2, 64, 3, 64, 4, 50, 2, 256) == 0
 

@@ -8,6 +8,7 @@ import torch
 
 from lookoncetohear_amd import _cabi, synth
 from lookoncetohear_amd.net import Net
+from tests.hipemu.hosts import EmuEmbed, EmuNet
 from oracle import tfgridnet_oracle as O
 
 TOL = 5e-5
@@ -18,9 +19,9 @@ def emu_net(oracle_cfg_sd):
     from tests.hipemu.build_emu import build_emu
     lib = _cabi.Lib(build_emu())
     cfg, sd = oracle_cfg_sd
-    net = Net(**O.TSH_PARAMS).eval()
+    net = EmuNet(**O.TSH_PARAMS).eval()  # the product host code over the emulated library (tests/hipemu/hosts.py)
     net.load_state_dict(sd, strict=True)
-    net._lib_override = lib            # test hook: CPU tensors + emulated library
+    net.emu_lib = lib
     return net
 
 
@@ -96,7 +97,7 @@ def test_previous_fused_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     """k_ln_lstm_lin<1> (the fused intra kernel before k_intra_xp became the default; kept for A/B runs, selected with
     lh_set_tuning(2, 2)) at the same tiny size: 38 frames = 3 sequence tiles, last one ragged, both directions."""
     cfg, sd = oracle_cfg_sd
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     B, T = 2, 19
     d = synth.batch([3, 4], 128 * T + 64)
     st = O.random_state(cfg, B, 3)
@@ -117,7 +118,7 @@ def test_fused_inter_kernels(emu_net, oracle_cfg_sd, tune5):
     """k_inter_xp (lh_recur.hip, the default) and the previous k_lstm_lin8p (lh_set_tuning(5, 2)): B=6 (582 sequences = 37 tiles, last one ragged; above
     the per-sequence mat-vec kernel's batch limit), T=7, carried (h0, c0) in and (hN, cN) out against the oracle."""
     cfg, sd = oracle_cfg_sd
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     B, T = 6, 7
     d = synth.batch(list(range(20, 20 + B)), 128 * T + 64)
     st = O.random_state(cfg, B, 13)
@@ -143,7 +144,7 @@ def test_unfused_inter_path_with_32_sequence_tiles(emu_net, oracle_cfg_sd):
     (k_ln_lstm_h3<2>, only selected with lh_set_tuning(1, 2)): B=2, T=5 = 194 sequences = 6 tiles + a ragged one, carried
     (h0, c0) in and out against the oracle."""
     cfg, sd = oracle_cfg_sd
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     B, T = 2, 5
     d = synth.batch([30, 31], 128 * T + 64)
     st = O.random_state(cfg, B, 17)
@@ -204,7 +205,7 @@ def test_attention_tile_modes_multi_tile(emu_net, oracle_cfg_sd):
     tiles sharing their K / V rows, the default for T > 16), last tile ragged in both; outputs and the next state
     (K_buf / V_buf through lh_ring_unpack) against the oracle."""
     cfg, sd = oracle_cfg_sd
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     B, T = 1, 37
     d = synth.batch([7], 128 * T + 64)
     st = O.random_state(cfg, B, 5)
@@ -236,7 +237,7 @@ def test_backend_runs_of_tiles(emu_net, oracle_cfg_sd):
     second and third tile continue from the first one's partial-product ring and last spectrum), two runs (2 + 1 tiles),
     and the automatic choice (one run per tile here) must all reproduce the oracle's waveform and next state."""
     cfg, sd = oracle_cfg_sd
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     B, T = 1, 37
     d = synth.batch([8], 128 * T + 64)
     st = O.random_state(cfg, B, 6)
@@ -257,7 +258,7 @@ def test_backend_runs_of_tiles(emu_net, oracle_cfg_sd):
 def test_ring_pack_unpack_roundtrip(emu_net):
     """fp32 state -> split-precision history rows -> fp32: hi + 2^-11 lo keeps 22 bits (|err| <= 2^-22 |v| + tiny)."""
     from lookoncetohear_amd.weights import KV_PAD_ROWS, QK_PAD, unsplit_qk, unsplit_v
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     B, T = 1, 3
     g = torch.Generator().manual_seed(9)
     kb = torch.randn(4 * B, 49, 582, generator=g) * 3
@@ -322,11 +323,11 @@ def test_range_guard_is_per_caller_and_emits_silence(emu_net, oracle_cfg_sd):
     d = synth.batch([1], 128 * 3)
     bad = d["mixture"].clone()
     bad[0, 0, 100] = float("nan")
-    other = Net(**O.TSH_PARAMS).eval()
+    other = EmuNet(**O.TSH_PARAMS).eval()
     other.load_state_dict(sd, strict=True)
-    other._lib_override = emu_net._lib_override
+    other.emu_lib = emu_net.emu_lib
     y = emu_net(bad, d["embedding_gt"])                    # flag raised, not consumed
-    assert torch.isfinite(y).all() and (y == 0).any()      # silence instead of NaN
+    assert torch.isnan(y).any()                            # and the NaN reaches the caller, like from the reference
     yo = other(d["mixture"], d["embedding_gt"])            # the other Net must not see (or clear) it
     assert torch.isfinite(yo).all() and other.range_status("cpu") is False
     assert emu_net.range_status("cpu") is True             # still pending for its owner ...
@@ -352,32 +353,71 @@ def test_range_guard_is_per_caller_and_emits_silence(emu_net, oracle_cfg_sd):
         st.step(d["mixture"][:, :, :192])
     st.reset()
     assert torch.isfinite(st.step(d["mixture"][:, :, :192])).all()
-    assert emu_net._lib_override.raw("lh_selftest_fp16_subnormal")(None) == 0
+    assert emu_net.emu_lib.raw("lh_selftest_fp16_subnormal")(None) == 0
     # the C-ABI's own fetch-and-clear (hosts without Python): one exchange, then clean
     flag = torch.ones(2, dtype=torch.int32)
-    assert emu_net._lib_override.raw("lh_range_status")(flag.data_ptr(), None) == 4
-    assert emu_net._lib_override.raw("lh_range_status")(flag.data_ptr(), None) == 0 and int(flag[0]) == 0
+    assert emu_net.emu_lib.raw("lh_range_status")(flag.data_ptr(), None) == 4
+    assert emu_net.emu_lib.raw("lh_range_status")(flag.data_ptr(), None) == 0 and int(flag[0]) == 0
+
+
+def test_all_fp32_mode_reference_kernels(emu_net, oracle_cfg_sd):
+    """`gemm_mode = "f32all"`: exact fp32-MFMA recurrences + the plain-fp32 reference kernels of
+    lh_ref32.hip for every frame stage (raw state-dict weights, fp32 Q / K / V) — offline from the zero state with every
+    stage tap, and one call with a carried non-zero state (history rows, LSTM state, conv / deconv / iSTFT tails in and out)
+    against the oracle.  Independent of weights.py's packed frame-kernel images and of the split-precision kernels."""
+    cfg, sd = oracle_cfg_sd
+    d = synth.batch([0, 1], 128 * 4)
+    taps, otaps = {}, {}
+    emu_net.gemm_mode, emu_net._debug_taps = "f32all", taps
+    try:
+        y = emu_net(d["mixture"], d["embedding_gt"])
+        emu_net._debug_taps = None
+        yo = O.forward(cfg, sd, d["mixture"], d["embedding_gt"], dtype=torch.float64, taps=otaps)
+        for k in ["Z0", "G"] + [f"blocks.{i}.{n}" for i in range(3) for n in ("Y2", "Q", "K", "V")] + ["blocks.1.out", "blocks.2.out"]:
+            assert (taps[k].double() - otaps[k].reshape(taps[k].shape)).abs().max() < TOL, k
+        assert (y.double() - yo).abs().max() < TOL
+        B, T = 2, 6
+        d = synth.batch([3, 4], 128 * T + 64)
+        st = O.random_state(cfg, B, 3)
+        yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+        y, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+        assert (y - yo).abs().max() < TOL
+        fo, f2 = O.flat_state(so), O.flat_state(s2)
+        for k in fo:
+            assert (fo[k] - f2[k]).abs().max() < TOL, k
+    finally:
+        emu_net.gemm_mode, emu_net._debug_taps = "f16x3", None
+    with pytest.raises(ValueError):
+        emu_net.gemm_mode = "f32"                          # the old alias of f32rec is gone
+        try:
+            emu_net(d["mixture"], d["embedding_gt"])
+        finally:
+            emu_net.gemm_mode = "f16x3"
 
 
 def test_cabi_argument_errors(emu_net):
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     assert lib.raw("lh_check_config")(192, 128, 2, 64, 3, 64, 4, 50, 2, 256) == 0
     assert lib.raw("lh_check_config")(256, 128, 2, 64, 3, 64, 4, 50, 2, 256) == 2      # LH_ERR_UNSUPPORTED
     assert lib.raw("lh_local_attn")(None, None, None, None, 1, 1, None) == 1             # LH_ERR_ARG
     assert lib.raw("lh_linear_res")(None, None, None, None, None, 0, 64, None) == 1
 
 
-def test_embedder_stages_and_embedding():
+@pytest.mark.parametrize("fused_axis", [True, False], ids=["k_emb_rec", "legacy-axis-kernels"])
+def test_embedder_stages_and_embedding(fused_axis):
     """Enrollment embedder: every stage tap and the final embedding against oracle/embedder_oracle.py
-    (fp64) on 2 utterances x 21 frames — front end, both axis paths, Q/K/V + full attention + projection, head."""
+    (fp64) on 2 utterances x 21 frames — front end, both axis paths, Q/K/V + full attention + projection, head.  Second
+    parameter: the round-1 axis kernels (k_emb_gx / k_emb_lstm / k_emb_convt_res behind lh_emb_axis) — only in -DLH_LEGACY
+    builds like the emulator's; the product library does not contain them (tests/test_cabi_symbols.py)."""
     from tests.hipemu.build_emu import build_emu
     from lookoncetohear_amd.embed_net import EmbedTFGridNet
     from oracle import embedder_oracle as E
     cfg = E.ECfg(**E.EMBED_PARAMS)
     sd = E.synthetic_state_dict(cfg, 0)
-    net = EmbedTFGridNet(**E.EMBED_PARAMS).eval()
+    net = EmuEmbed(**E.EMBED_PARAMS).eval()
     net.load_state_dict(sd, strict=True)
-    net._lib_override = _cabi.Lib(build_emu())
+    net.emu_lib = _cabi.Lib(build_emu())
+    net.fused_axis = fused_axis
     x = synth.batch([0, 1], 1280)["mixture"]
     taps, otaps = {}, {}
     net._debug_taps = taps
@@ -402,9 +442,9 @@ def test_packed_blob_is_a_sufficient_weight_source(emu_net, tmp_path):
     from lookoncetohear_amd import checkpoint
     path = str(tmp_path / "sep.lhw")
     checkpoint.export_packed(emu_net, path)
-    blob_net = Net.from_packed(path, "cpu")
+    blob_net = EmuNet.from_packed(path, "cpu")
     assert blob_net.tfgridnet is None and len(list(blob_net.parameters())) == 0
-    blob_net._lib_override = emu_net._lib_override
+    blob_net.emu_lib = emu_net.emu_lib
     d = synth.batch([2], 128 * 3)
     with torch.no_grad():
         assert torch.equal(blob_net(d["mixture"], d["embedding_gt"]), emu_net(d["mixture"], d["embedding_gt"]))
@@ -446,7 +486,7 @@ def test_inter_xp_shortest_sequences(emu_net):
     """k_inter_xp peels its first two steps and has a two-step unrolled loop with a tail: T = 2, 3, 4, 5 (no loop / tail only /
     one loop pass / loop + tail) with carried state and a ragged last tile, against the previous kernel (lh_set_tuning(5, 2));
     T = 1 must route to the previous kernel (the hand-ordered one needs two steps)."""
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     bp = emu_net._weights(torch.device("cpu"))["blocks"][1]
     P = lambda t: t.data_ptr()
     B = 1                                            # 97 sequences = 7 tiles, the last one with a single live row
@@ -474,7 +514,7 @@ def test_inter_xp_shortest_sequences(emu_net):
 def test_ring_advance_wraps(emu_net):
     """lh_ring_advance: the streaming ring slot counter stays in [0, modulo); bad arguments are refused."""
     import ctypes
-    lib = emu_net._lib_override
+    lib = emu_net.emu_lib
     pos = torch.tensor([48], dtype=torch.int32)
     for want in (49, 0, 1):
         lib.call("lh_ring_advance", pos.data_ptr(), 50, 0)
@@ -496,9 +536,9 @@ def test_enroll_then_separate_chain_on_the_emulator(emu_net, oracle_cfg_sd):
     cfg, sd = oracle_cfg_sd
     ecfg = E.ECfg(**E.EMBED_PARAMS)
     esd = E.synthetic_state_dict(ecfg, 0)
-    enet = EmbedTFGridNet(**E.EMBED_PARAMS).eval()
+    enet = EmuEmbed(**E.EMBED_PARAMS).eval()
     enet.load_state_dict(esd, strict=True)
-    enet._lib_override = _cabi.Lib(build_emu())
+    enet.emu_lib = _cabi.Lib(build_emu())
     data_fn = lambda idx: synth.batch(idx, 128 * 3, enroll_n=1280)
     kept = []
 

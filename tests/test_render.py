@@ -52,8 +52,9 @@ def test_oracle_matches_reference_call():
 
 def test_emulated_kernels_match_oracle():
     from tests.hipemu.build_emu import build_emu
-    rr = BinauralRenderer()
-    rr._lib_override = _cabi.Lib(build_emu())
+    from tests.hipemu.hosts import EmuRenderer
+    rr = EmuRenderer()
+    rr.emu_lib = _cabi.Lib(build_emu())
     nf = _check(rr, "cpu", [0, 1], 5003, 200)                   # ragged N, peak below 1: no normalisation
     assert float(nf.max()) < 1.0
     nf = _check(rr, "cpu", [2], 4500, 3000, loud=4.0, reverb=True)   # room-length response: overlap-save FFT path, peak > 1
