@@ -800,6 +800,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)     # RCCL over xGMI
 
     from lookoncetohear_amd import synth, _cabi
+    for kv in filter(None, args.tune.split(",")):                   # A/B switches of the library (every mode)
+        k, v = kv.split("=")
+        assert _cabi.load().raw("lh_set_tuning")(int(k), int(v)) == 0, f"lh_set_tuning({k}, {v}) refused"
     if args.mode == "embed":
         _cabi.load()
         return bench_embed(args, dev, rank, world, dist)
@@ -816,9 +819,6 @@ def main():
     net = net.to(dev)
     if args.gemm:
         net.gemm_mode = args.gemm
-    for kv in filter(None, args.tune.split(",")):
-        k, v = kv.split("=")
-        assert _cabi.load().raw("lh_set_tuning")(int(k), int(v)) == 0
 
     if args.mode == "stream":
         return bench_stream(args, net, dev, rank, world)

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
     __shared__ float sp[4][TQ][NB];            // per-wave partial scores, band-relative columns (d, l15)
     __shared__ __attribute__((aligned(16))) _Float16 ph[16 * MQ][AT_PP];
     __shared__ __attribute__((aligned(16))) _Float16 pl[16 * MQ][AT_PP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     // XCD-aware placement: the tiles of (batch, head) bh all run on XCD bh % 8
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
     const int bh = (kk / ntt) * 8 + xcd;

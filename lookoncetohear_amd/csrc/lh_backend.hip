@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(BE_NT) k_deconv_istft(const float* __restrict_
     // synthesis frames: only live after the frame loop, in the space of the (then dead) hi A images
     static_assert(sizeof(float) * BE_NJ * NSRC * BE_FP <= sizeof(_Float16) * 2 * FR_A, "frs must fit in ahi");
     float (*frs)[NSRC][BE_FP] = reinterpret_cast<float (*)[NSRC][BE_FP]>(ahi);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
 
     // B fragments: the deconv taps [64 -> 48 columns] (3 column tiles x 2 k-steps, 6 KB) sit in LDS in fragment order;
     // the synthesis filterbank tiles 2w, 2w+1 (of 12; 112 registers) are fetched from L2 once per tile, right before

@@ -89,7 +89,22 @@ __device__ __forceinline__ void lstm_cell_pre(float ai, float af, float ag, floa
     c = cc;
     h = og * tanh_f(cc);
 }
+// Wave index of a thread as a SCALAR.  `tid >> 6` is wave-uniform, but the compiler's uniformity analysis does not know the
+// wavefront size: every condition and address derived from it counted as divergent — exec-masked branches (s_and_saveexec +
+// s_cbranch) around whole MFMA groups "if (wave + 4 < NQKV / 16)", per-lane address arithmetic for per-wave offsets (round 5,
+// found by reading the ISA of k_gemm_nt: 137 s_and_saveexec for 48 MFMAs; k_local_attn<3,2,40>: 279).  v_readfirstlane
+// makes it an SGPR: scalar branches, scalar address arithmetic, fewer VGPRs.
+__device__ __forceinline__ int wave_id(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
+
 __device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
+// PReLU in two instructions for a slope known to be <= 1 / > 1 (a wave-uniform property of the layer, tested once per
+// kernel): for a <= 1 the two branches x and a*x never cross the wrong way — x >= 0: a*x <= x; x < 0: a*x >= x — so
+// prelu(x) = max(x, a*x); for a > 1 it is min(x, a*x).  The compare + select form above costs three (frame kernels are
+// VALU-bound).  NaN: max / min return the non-NaN operand, but x = NaN makes both operands NaN.
+template <bool SLOPE_LE_1>
+__device__ __forceinline__ float prelu_mm(float x, float a) {
+    return SLOPE_LE_1 ? __builtin_fmaxf(x, a * x) : __builtin_fminf(x, a * x);
+}
 
 // sum over the 64 lanes of a wave (every lane gets the total): 4 DPP row steps + 2 cross-row shuffles
 __device__ __forceinline__ float wave_sum(float v);

@@ -30,7 +30,7 @@ constexpr float ESPLIT = 1.0f;
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_emb_std(const float* __restrict__ x, float* __restrict__ inv_std, int n) {
     __shared__ double red[2][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
     const float* xb = x + (long)blockIdx.x * n;
     double s = 0.0, ss = 0.0;
     for (int i = tid; i < n; i += 256) { const double v = xb[i]; s += v; ss += v * v; }
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256, 1) k_emb_stft_conv(const float* __restric
     __shared__ float spec[2 * NMIC][EM_NJ][EM_SROW];
     __shared__ __attribute__((aligned(16))) float outs[EF * EM_OP];
     __shared__ double gred[2][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
 
     float wf[3][EM_KC];
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_gx(const _Float16* __restrict__ 
     __shared__ __attribute__((aligned(16))) _Float16 ahi[8 * GX_RP * 8];
     __shared__ __attribute__((aligned(16))) _Float16 alo[8 * GX_RP * 8];
     __shared__ __attribute__((aligned(16))) float cs[64 * GX_CSP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int chunk = blockIdx.y;
     const _Float16* xh = xs;
     const _Float16* xl = xs + rows_x * C;
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_lstm(const float* __restrict__ g
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * 16 * EL_AP];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * 16 * EL_AP];
     __shared__ __attribute__((aligned(16))) float hf[2 * 16 * EL_HP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int dir = blockIdx.y, s0 = blockIdx.x * 16;
     const int unit = wave * 16 + l15;
     const int rl = tid >> 4, q = tid & 15;
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt_res(const float* __restric
     __shared__ __attribute__((aligned(16))) _Float16 ahi[KS * 4 * RP * 8];
     __shared__ __attribute__((aligned(16))) _Float16 alo[KS * 4 * RP * 8];
     __shared__ __attribute__((aligned(16))) float cs[RP * CSP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     f16x8 wh[KS], wl[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
     __shared__ __attribute__((aligned(16))) _Float16 ring[ER_RING * ER_POS];
     __shared__ __attribute__((aligned(16))) _Float16 himg[2 * ER_POS];
     __shared__ __attribute__((aligned(16))) float bsm[256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int dir = blockIdx.y, s0 = blockIdx.x * 16;
     const int L = P + EKS - 1;
     const long hrows = (long)nseq * P;
@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
     __shared__ __attribute__((aligned(16))) _Float16 ahi[16 * RP * 8];
     __shared__ __attribute__((aligned(16))) _Float16 alo[16 * RP * 8];
     __shared__ __attribute__((aligned(16))) float cs[RT * CSP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     f16x8 wh[KS], wl[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -1024,7 +1024,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_qkv(const float* __restrict__ y,
     __shared__ __attribute__((aligned(16))) _Float16 ahi[EFR_A];
     __shared__ __attribute__((aligned(16))) _Float16 alo[EFR_A];
     __shared__ float ys[EF * YP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     f16x8 wh0[2], wl0[2], wh1[2], wl1[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1073,7 +1073,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_proj(const float* __restrict__ m
     __shared__ __attribute__((aligned(16))) _Float16 alo[EFR_A];
     __shared__ __attribute__((aligned(16))) float ys[EF * YP];
     __shared__ float red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     f16x8 wh[2], wl[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1198,7 +1198,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
                                                     long strideC, float scale, int nbatch, int tiles_m, int tiles_n,
                                                     int Bn, int T) {
     __shared__ __attribute__((aligned(16))) _Float16 sm[2][4][GM_IMG];      // [stage][A hi, A lo, B hi, B lo]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware decode: consecutive workgroup ids go round-robin over the 8 XCDs; keep a batch on one XCD
     const int ntile = tiles_m * tiles_n;
@@ -1229,6 +1229,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
     fetch(0);
     const int nk = K / 32;
     const int jn_live = min(4, max(0, (N - (n0 + wn * 64) + 15) / 16));      // 16-column sub-tiles of this wave with any column < N
+    // (round 5, reading the ISA: derived from threadIdx this wave-uniform value is treated as divergent and EVERY MFMA of the
+    // loop sits in its own exec-masked branch — s_and_saveexec + s_cbranch around each of the 48; k_gemm_nt2 below fixes it.
+    // This kernel is kept as it shipped in rounds 1-4 for the A/B, lh_set_tuning(17, 0).)
 #pragma unroll 1
     for (int ks = 0; ks < nk; ++ks) {
         _Float16* buf = &sm[ks & 1][0][0];
@@ -1272,6 +1275,138 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
                 const int row = m0 + wm * 64 + i * 16 + g4 * 4 + r;
                 if (row < M && col < N) {
                     const float val = (am[i][jn][r] + ac[i][jn][r] * (1.0f / ESPLIT)) * scale;
+                    if (EPI == 0) {
+                        Cm[(long)batch * strideC + (long)row * ldc + col] = val;
+                    } else {                     // batch = h*Bn + b, row = frame, col = f*16 + v
+                        const int hd = batch / Bn, b = batch % Bn;
+                        Cm[(((long)b * T + row) * EF + (col >> 4)) * C + hd * VD + (col & 15)] = val;
+                    }
+                }
+            }
+        }
+}
+
+// Round 5 ("change the structure"): the same product with the B operand OUT of LDS.  k_gemm_nt above moves
+// both operands' hi and lo images through LDS — per CU and 32-wide k-step 64 KB of ds_read_b128 plus 64 KB of staging
+// writes (two workgroups) against 1536 cycles of matrix-pipe time: 1024 + 512 LDS cycles, i.e. the LDS pipe is as busy as
+// the matrix pipe and every hiccup of one stalls the other (0.6 - 0.78 PFLOP/s executed, 0.34 of what the matrix core
+// sustains).  Both operands are K-contiguous rows (NT), so a lane's B fragment — row n0 + l15, halves 32 ks + 8 g4 .. + 7 —
+// is 16 contiguous bytes of global memory: B fragments are loaded straight into registers, TWO k-steps ahead (a three-slot
+// register ring; the two waves that share a column block hit the same lines in L1 / L2), and only A goes through LDS
+// (global -> registers -> double-buffered LDS as before).  LDS traffic per MFMA halves, the staging of a stage is 4
+// ds_write_b128 per thread instead of 8, and one accumulator set per tile (the un-rescaled split needs no second chain:
+// the three products of a tile are issued 16 MFMAs apart) leaves the registers for the ring.
+// RAGGED = false: every 16-column sub-tile is computed (straight-line MFMAs; columns >= N run on a clamped duplicate row and
+// are not stored); RAGGED = true: sub-tiles without a live column are skipped with SCALAR branches (`jn_live` through
+// v_readfirstlane: derived from threadIdx the compiler took it for divergent and wrapped every MFMA of k_gemm_nt in its own
+// exec-masked branch).  Two kernels, not two paths in one: the register allocator sees one loop each.  The workgroup's
+// column tile is tn_begin + (tile % tiles_n): the P.V product (N = 1040 = 8 x 128 + 16) runs its 8 full column tiles on
+// the straight-line kernel and the ninth on the ragged one.
+template <int EPI, bool RAGGED>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt2(const _Float16* __restrict__ A, const _Float16* __restrict__ Bm,
+                                                     float* __restrict__ Cm, int M, int N, int K, int lda, int ldb,
+                                                     long strideA, long strideB, long imgA, long imgB, int ldc,
+                                                     long strideC, float scale, int nbatch, int tiles_m, int tiles_n,
+                                                     int tn_begin, int Bn, int T) {
+    __shared__ __attribute__((aligned(16))) _Float16 sm[2][2][GM_IMG];      // [stage][A hi, A lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntile = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int batch = (j / ntile) * 8 + xcd, tile = j % ntile;
+    if (batch >= nbatch) return;
+    const int m0 = (tile / tiles_n) * 128, n0 = (tn_begin + tile % tiles_n) * 128;
+    const _Float16* Ab = A + (long)batch * strideA;
+    const _Float16* Bb = Bm + (long)batch * strideB;
+
+    // A staging: 128 rows x 4 k-blocks of 16 bytes per image = 512 items, 2 per thread and image
+    const int sr = tid >> 2, sb = tid & 3;
+    const long a_off0 = (long)min(m0 + sr, M - 1) * lda + sb * 8, a_off1 = (long)min(m0 + sr + 64, M - 1) * lda + sb * 8;
+    const int s_idx0 = (sb * GM_RP + sr) * 8, s_idx1 = (sb * GM_RP + sr + 64) * 8;
+    f16x8 st[4];
+    auto fetch_a = [&](int k0) {
+        st[0] = *reinterpret_cast<const f16x8*>(Ab + a_off0 + k0);        st[1] = *reinterpret_cast<const f16x8*>(Ab + a_off1 + k0);
+        st[2] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off0 + k0); st[3] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off1 + k0);
+    };
+    // B fragments of this wave's four 16-column sub-tiles, straight from global memory (rows clamped: dead columns of the
+    // last tile compute on a duplicate row and are never stored)
+    const int jn_live = __builtin_amdgcn_readfirstlane(min(4, max(0, (N - (n0 + wn * 64) + 15) / 16)));   // sub-tiles with any column < N
+    int b_off[4];                            // halves from the batch's panel (a panel is < 2^31 halves)
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) b_off[jn] = min(n0 + wn * 64 + jn * 16 + l15, N - 1) * ldb + g4 * 8;
+    f16x8 bh[3][4], bl[3][4];
+    auto fetch_b = [&](auto slot_, int k0) {
+        constexpr int slot = decltype(slot_)::value;
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+            bh[slot][jn] = *reinterpret_cast<const f16x8*>(Bb + b_off[jn] + k0);
+            bl[slot][jn] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off[jn] + k0);
+        }
+    };
+    f32x4 am[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) am[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = K / 32;
+    fetch_a(0);
+    fetch_b(std::integral_constant<int, 0>{}, 0);
+    if (nk > 1) fetch_b(std::integral_constant<int, 1>{}, 32);
+
+    auto stage = [&](int ks, auto slot_) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_)::value;
+        constexpr bool FULL = !RAGGED;
+        _Float16* buf = &sm[ks & 1][0][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx0]) = st[2 * i];
+            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx1]) = st[2 * i + 1];
+        }
+        __syncthreads();
+        if (ks + 1 < nk) fetch_a((ks + 1) * 32);
+        if (ks + 2 < nk) fetch_b(std::integral_constant<int, (slot + 2) % 3>{}, (ks + 2) * 32);
+        // two row-tile pairs (A fragments of a pair: 16 registers); small products first; the three products of one tile
+        // are 8 MFMAs apart (no back-to-back dependent MFMAs)
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            f16x8 ah[2], al[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = (g4 * GM_RP + wm * 64 + (2 * ip + i) * 16 + l15) * 8;
+                ah[i] = *reinterpret_cast<const f16x8*>(&buf[idx]);
+                al[i] = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn)
+                        if (FULL || jn < jn_live)
+                            am[2 * ip + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                p == 0 ? al[i] : ah[i], p == 1 ? bl[slot][jn] : bh[slot][jn], am[2 * ip + i][jn], 0, 0, 0);
+        }
+    };
+    int ks = 0;
+#pragma unroll 1
+    for (; ks + 3 <= nk; ks += 3) {
+        stage(ks, std::integral_constant<int, 0>{});
+        stage(ks + 1, std::integral_constant<int, 1>{});
+        stage(ks + 2, std::integral_constant<int, 2>{});
+    }
+    if (ks < nk) stage(ks, std::integral_constant<int, 0>{});
+    if (ks + 1 < nk) stage(ks + 1, std::integral_constant<int, 1>{});
+    // epilogue: lane holds rows g4*4 + r, column l15 of each 16 x 16 tile -> 64-byte row segments
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+            const int col = n0 + wn * 64 + jn * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + g4 * 4 + r;
+                if (row < M && col < N) {
+                    const float val = am[i][jn][r] * scale;
                     if (EPI == 0) {
                         Cm[(long)batch * strideC + (long)row * ldc + col] = val;
                     } else {                     // batch = h*Bn + b, row = frame, col = f*16 + v
@@ -1382,7 +1517,7 @@ __global__ void __launch_bounds__(512, 1) k_emb_head(const float* __restrict__ z
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * 4 * EH_ROWS * 8];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * 4 * EH_ROWS * 8];
     __shared__ float rs[8][EH_ROWS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int b = blockIdx.y, t0 = blockIdx.x * EH_ROWS;
     const float* zb = z + (long)b * T * EH_K;
 
@@ -1553,9 +1688,11 @@ extern "C" int lh_probe_er_trace_read(unsigned long long* host_dst) {
 #endif
 namespace lh {
 static int g_rec_prio = 0;              // lh_set_tuning key 16: issue priority for k_emb_rec's on-chain MFMAs (0 = off)
+static int g_gemm_v = 1;                // lh_set_tuning key 17: attention GEMM variant (1 = k_gemm_nt2, 0 = k_gemm_nt)
 int emb_set(int key, int value) {
-    if (key != 16 || value < 0 || value > 1) return LH_ERR_ARG;
-    g_rec_prio = value;
+    if ((key != 16 && key != 17) || value < 0 || value > 1) return LH_ERR_ARG;
+    if (key == 16) g_rec_prio = value;
+    else g_gemm_v = value;
     return LH_OK;
 }
 }  // namespace lh
@@ -1624,6 +1761,12 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
     hipLaunchKernelGGL(k_emb_vt, dim3(Tp / 64, (EDV + 63) / 64, nb), dim3(256), 0, st, v, (_Float16*)vt, T, Tp, img_vt);
     const int nb8 = (nb + 7) / 8 * 8;
     const int tm = (T + 127) / 128;
+    // g_gemm_v (lh_set_tuning key 17): 1 = k_gemm_nt2 (B operand straight from global memory, round 5), 0 = k_gemm_nt (A/B)
+    if (g_gemm_v)     // scores: every column tile on the straight-line kernel (the last one wastes <= 1 sub-tile of 80)
+        hipLaunchKernelGGL((k_gemm_nt2<0, false>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc,
+                           T, T, EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
+                           1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T);
+    else
     hipLaunchKernelGGL((k_gemm_nt<0>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc, T, T,
                        EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
                        1.0f / sqrtf((float)EDQK), nb, tm, tm, B, T);
@@ -1646,6 +1789,15 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
 #undef LH_SOFTMAX_REG
     }
     const int tn = (EDV + 127) / 128;
+    if (g_gemm_v) {
+        const int tn_full = EDV / 128;            // 8 full column tiles on the straight-line kernel, the ragged ninth on its own
+        hipLaunchKernelGGL((k_gemm_nt2<1, false>), dim3(nb8 * tm * tn_full), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt,
+                           merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn_full, 0, B, T);
+        if (tn > tn_full)
+            hipLaunchKernelGGL((k_gemm_nt2<1, true>), dim3(nb8 * tm * (tn - tn_full)), dim3(256), 0, st, (const _Float16*)p,
+                               (const _Float16*)vt, merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L,
+                               1.0f, nb, tm, tn - tn_full, tn_full, B, T);
+    } else
     hipLaunchKernelGGL((k_gemm_nt<1>), dim3(nb8 * tm * tn), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt, merged, T,
                        EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn, B, T);
     hipLaunchKernelGGL(k_emb_proj, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, st, merged, (const _Float16*)wproj_pk,

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(FE_NTH, 1) k_stft_conv_in(const float* __restr
     // linear, so the scale is undone once, on the conv accumulator (the bias joins after it).  A quiet recording (x 1e-4)
     // keeps its 22 bits, a hot one (x 1e3) does not overflow the fp16 halves.
     __shared__ float tmax[FE_NTH / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
 
     // resident B fragments: filterbank tiles wave, wave + 8; conv weights of channel tile wave & 3
     f16x8 wfh[2][FE_KS], wfl[2][FE_KS];
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_embed_proj(const float* __restrict__ em
                                                      const float* __restrict__ bias, float* __restrict__ raw, int B) {
     constexpr int N = C * NF;
     __shared__ __attribute__((aligned(16))) float es[EP_NB][SPK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
     const int b0 = blockIdx.y * EP_NB;
     for (int i = tid; i < EP_NB * SPK; i += 256) {
         const int bb = min(b0 + i / SPK, B - 1);

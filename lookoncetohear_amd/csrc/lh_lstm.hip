@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) k_ln_lstm(const float* __restrict__ x, co
                                                  int nstep, int sdiv, int so, int si, int ps, int ldh) {
     constexpr int NS = 16 * MT;
     __shared__ __attribute__((aligned(16))) float abuf[2 * 4 * NS * LS_PAD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
     const int dir = blockIdx.y;
     const int s0 = blockIdx.x * NS;
     const int g4 = lane >> 4, l15 = lane & 15;
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_h3(const float* __restrict__
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * LH_AP];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * LH_AP];
     __shared__ __attribute__((aligned(16))) float hf[2 * NS * LH_HP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
     const int dir = blockIdx.y;
     const int s0 = blockIdx.x * NS;
     const int g4 = lane >> 4, l15 = lane & 15;
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) k_ln_lstm_lin(const float* __restrict_
 #else
 #define LH_STAMP(k) do { } while (0)
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
     const int s0 = blockIdx.x * NS;
     const int g4 = lane >> 4, l15 = lane & 15;
     const int q = tid & 15;
@@ -1058,7 +1058,7 @@ extern "C" int lh_set_tuning(int key, int value) {
     if (key == 4) return lh::attn_set_mq(value);
     if (key == 6) return lh::backend_set_runs(value);
     if (key >= 7 && key < 16) return lh::xp_set(key, value);      // lh_recur.hip switches
-    if (key == 16) return lh::emb_set(key, value);                // lh_embed.hip: k_emb_rec issue priority
+    if (key == 16 || key == 17) return lh::emb_set(key, value);   // lh_embed.hip: k_emb_rec issue priority, attention GEMM variant
     if (key < 0 || key >= 8) return LH_ERR_ARG;
 #if defined(LH_LEGACY)
     if (key == 3) lh::g_dephase = value;

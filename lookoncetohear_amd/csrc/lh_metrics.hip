@@ -24,7 +24,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __global__ void __launch_bounds__(256) k_metric_moments(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                         const float* __restrict__ mix, double* __restrict__ part, int n) {
     __shared__ double red[4][MT_NM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
     const long base = (long)blockIdx.y * n;
     const int per = ((n + MT_CHUNKS - 1) / MT_CHUNKS + 3) & ~3;
     const int lo = blockIdx.x * per, hi = min(n, lo + per);
@@ -84,7 +84,7 @@ __device__ __forceinline__ double si_snr_from_moments(double sp, double st, doub
 __global__ void __launch_bounds__(256) k_metric_finish(const double* __restrict__ part, const float* __restrict__ emb,
                                                        const float* __restrict__ emb_gt, float* __restrict__ rows,
                                                        double* __restrict__ sums, int B, int n, int edim) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
     double* rows64 = const_cast<double*>(part) + (long)B * 2 * MT_CHUNKS * MT_NM;     // [B][3] tail of the scratch
     for (int b = wave; b < B; b += 4) {
         double m = 0.0;                                       // lane = ch * 8 + k (< 16): moment k of channel ch

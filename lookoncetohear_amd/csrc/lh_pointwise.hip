@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h,
     __shared__ __attribute__((aligned(16))) _Float16 ahi[KS * 4 * RP * 8];
     __shared__ __attribute__((aligned(16))) _Float16 alo[KS * 4 * RP * 8];
     __shared__ __attribute__((aligned(16))) float cs[RP * CP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
 
     f16x8 wh[KS], wl[KS];
     load_w<KS>(w_pk, wave, lane, wh, wl);              // wave w owns output columns 16w .. 16w+15
@@ -83,50 +83,45 @@ __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h,
 }
 
 // Per-head LayerNorm + split-precision store, one wave per head (N values held flat, index i = f*D + e = the
-// reference's reshape order, in LDS at ysrc[0 .. 8*NOCT); entries >= N are zero; gw / gb are zero-padded to 8*NOCT so
-// pad outputs are exactly 0).  A lane owns octets lane + 64 k; out-of-range slots are clamped to the last octet (the
-// code stays branch-free so the affine loads of later slots are issued under the arithmetic of earlier ones) and
-// only their statistics contributions and stores are masked.  Output formats (lh_common.h):
-//   VLAYOUT = 0 (Q / K rows):  octet o -> [hi 8 | lo 8]
-//   VLAYOUT = 1 (V rows):      octet o -> quads 2o, 2o+1, each [hi 4 | lo 4]
-template <int N, int NOCT>
+// reference's reshape order, in LDS at ysrc[0 .. 4*NQ); entries >= N are zero; gw / gb are zero-padded to 4*NQ so
+// pad outputs are exactly 0).  Round 5: a lane owns QUADS lane + 64 k (rounds 1-4: octets — 76 and 194 octets on 64
+// lanes left 34 % of the slots dead, and this phase is 60 % of the VALU-bound kernel's vector instructions; 152 and 388
+// quads leave 18 %); out-of-range slots are clamped to the last quad (the code stays branch-free so the affine loads of
+// later slots are issued under the arithmetic of earlier ones) and only their statistics contributions and stores are
+// masked.  Output formats (lh_common.h):
+//   VLAYOUT = 0 (Q / K rows):  quad qd of octet o = qd >> 1 -> hi 4 at [16 o + 4 (qd & 1)], lo 4 eight halves behind
+//   VLAYOUT = 1 (V rows):      quad qd -> [hi 4 | lo 4] at [8 qd]
+template <int N, int NQ>
 struct HeadLN {
-    static constexpr int NS = (NOCT + 63) / 64;
-    float x[NS][8];
-    float4 w[NS][2], b[NS][2];
+    static constexpr int NS = (NQ + 63) / 64;
+    float x[NS][4];
+    float4 w[NS], b[NS];
 
-    __device__ __forceinline__ static int oct(int lane, int k) { return min(lane + 64 * k, NOCT - 1); }
-    __device__ __forceinline__ static bool live(int lane, int k) { return lane + 64 * k < NOCT; }
+    __device__ __forceinline__ static int quad(int lane, int k) { return min(lane + 64 * k, NQ - 1); }
+    __device__ __forceinline__ static bool live(int lane, int k) { return 64 * k + 63 < NQ || lane + 64 * k < NQ; }
+    // slot k holds only values of the row (no pad, no dead lane): its statistics need no mask
+    static constexpr bool inside(int k) { return 4 * (64 * k + 63) + 3 < N; }
 
-    // LDS -> registers; returns the lane's partial sum.  `zero8` = 8 floats of zeros in LDS (16-byte aligned): slots past
+    // LDS -> registers; returns the lane's partial sum.  `zero4` = 4 floats of zeros in LDS (16-byte aligned): slots past
     // the row read those instead, so nothing has to be masked out of the sum.
-    // (Rounds 1-2 drained all reads with an inline s_waitcnt lgkmcnt(0) here: ~0.3 % of the V rows had come out with a wrong
-    // mean whenever two workgroups shared a CU, read as an LDS return-order problem.  It was the packed-fp32 accumulation
-    // chain the vectoriser built from these adds — profiles/r03c_packed_fp32_corruption.txt; the library is compiled
-    // without packed fp32 now and the drain is gone: QKV 1.08 -> 1.03 ms per step.)
-    __device__ __forceinline__ float read(const float* ysrc, const float* zero8, int lane) {
+    __device__ __forceinline__ float read(const float* ysrc, const float* zero4, int lane) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const float* src = live(lane, k) ? ysrc + 8 * (lane + 64 * k) : zero8;
+            const float* src = live(lane, k) ? ysrc + 4 * (lane + 64 * k) : zero4;
             const float4 a = *reinterpret_cast<const float4*>(src);
-            const float4 c = *reinterpret_cast<const float4*>(src + 4);
             x[k][0] = a.x; x[k][1] = a.y; x[k][2] = a.z; x[k][3] = a.w;
-            x[k][4] = c.x; x[k][5] = c.y; x[k][6] = c.z; x[k][7] = c.w;
         }
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < NS; ++k)
-            s += (x[k][0] + x[k][1]) + (x[k][2] + x[k][3]) + (x[k][4] + x[k][5]) + (x[k][6] + x[k][7]);
+        for (int k = 0; k < NS; ++k) s += (x[k][0] + x[k][1]) + (x[k][2] + x[k][3]);
         return s;
     }
     __device__ __forceinline__ void load_affine(const float* __restrict__ gw, const float* __restrict__ gb, int lane) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const int o = oct(lane, k);
-            w[k][0] = *reinterpret_cast<const float4*>(&gw[8 * o]);
-            w[k][1] = *reinterpret_cast<const float4*>(&gw[8 * o + 4]);
-            b[k][0] = *reinterpret_cast<const float4*>(&gb[8 * o]);
-            b[k][1] = *reinterpret_cast<const float4*>(&gb[8 * o + 4]);
+            const int o = quad(lane, k);
+            w[k] = *reinterpret_cast<const float4*>(&gw[4 * o]);
+            b[k] = *reinterpret_cast<const float4*>(&gb[4 * o]);
         }
     }
     __device__ __forceinline__ float center(float mean, int lane) {             // x -= mean; lane's partial sum of squares
@@ -134,11 +129,11 @@ struct HeadLN {
 #pragma unroll
         for (int k = 0; k < NS; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 const float d = x[k][e] - mean;
                 x[k][e] = d;
-                if (k < NS - 1 && 8 * (64 * k + 63) + 7 < N) v += d * d;            // slot entirely inside the row
-                else v += (8 * (lane + 64 * k) + e < N) ? d * d : 0.f;
+                if (inside(k)) v = fmaf(d, d, v);
+                else v += (4 * (lane + 64 * k) + e < N) ? d * d : 0.f;
             }
         return v;
     }
@@ -147,25 +142,21 @@ struct HeadLN {
     __device__ __forceinline__ void store(float rstd, _Float16* dst, int lane) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const float wv[8] = {w[k][0].x, w[k][0].y, w[k][0].z, w[k][0].w, w[k][1].x, w[k][1].y, w[k][1].z, w[k][1].w};
-            const float bv[8] = {b[k][0].x, b[k][0].y, b[k][0].z, b[k][0].w, b[k][1].x, b[k][1].y, b[k][1].z, b[k][1].w};
-            f16x8 h8, l8;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                f16x2_t h2, l2;
-                split_pair(x[k][e] * rstd * wv[e] + bv[e], x[k][e + 1] * rstd * wv[e + 1] + bv[e + 1], h2, l2);
-                h8[e] = h2[0]; h8[e + 1] = h2[1];
-                l8[e] = l2[0]; l8[e + 1] = l2[1];
-            }
-            f16x8 o0 = h8, o1 = l8;
-            if (VLAYOUT) {
-                o0 = f16x8{h8[0], h8[1], h8[2], h8[3], l8[0], l8[1], l8[2], l8[3]};
-                o1 = f16x8{h8[4], h8[5], h8[6], h8[7], l8[4], l8[5], l8[6], l8[7]};
-            }
+            const float wv[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+            const float bv[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
+            f16x2_t h01, l01, h23, l23;
+            split_pair(x[k][0] * rstd * wv[0] + bv[0], x[k][1] * rstd * wv[1] + bv[1], h01, l01);
+            split_pair(x[k][2] * rstd * wv[2] + bv[2], x[k][3] * rstd * wv[3] + bv[3], h23, l23);
             if (live(lane, k)) {
-                const int o = lane + 64 * k;
-                *reinterpret_cast<f16x8*>(&dst[16 * o]) = o0;
-                *reinterpret_cast<f16x8*>(&dst[16 * o + 8]) = o1;
+                const int qd = lane + 64 * k;
+                if (VLAYOUT) {
+                    *reinterpret_cast<f16x8*>(&dst[8 * qd]) =
+                        f16x8{h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+                } else {
+                    _Float16* d = dst + 8 * qd - 4 * (qd & 1);
+                    *reinterpret_cast<f16x4*>(d) = f16x4{h01[0], h01[1], h23[0], h23[1]};
+                    *reinterpret_cast<f16x4*>(d + 8) = f16x4{l01[0], l01[1], l23[0], l23[1]};
+                }
             }
         }
     }
@@ -198,7 +189,7 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     // the input is the un-normalised residual stream: every row is scaled by its own power of two before the split and
     // the accumulator rows by the inverse (frame_store_scaled, lh_split.h) — Linear is linear, the bias joins afterwards
     __shared__ __attribute__((aligned(16))) float rinv[FR_RP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
 
     // wave w owns output-column tiles w and w+4 (of 7): Q|K|V columns 16w.. and 64+16w..
     f16x8 wh0[2], wl0[2], wh1[2], wl1[2];
@@ -209,6 +200,7 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     const float bz0 = bias[c0], bz1 = bias[two ? c1 : c0];
     const float sq = slopes[0], sk = slopes[1], sv = slopes[2];
     const float a0 = c0 < NH * E ? sq : (c0 < 2 * NH * E ? sk : sv);      // PReLU slope of column c0; c1 is always V
+    const bool le1 = sq <= 1.0f && sk <= 1.0f && sv <= 1.0f;            // kernel-uniform: PReLU = max(x, a x)
     // where this lane's columns land in yf: element (f, c) -> base + f * stride
     int base0, str0;
     if (c0 < NH * E) { base0 = (c0 / E) * YQS + c0 % E; str0 = E; }
@@ -236,28 +228,39 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
         QKV_STAMP(1);
         if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
-        // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check
-        auto row_tile = [&](int m, auto checked) {
-            const f32x4 r0 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh0, wl0, 0.f);
+        // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check.
+        // Round 5 (the kernel is VALU-bound): one accumulator chain per tile (no am + ac adds) and PReLU
+        // as max / min (two instructions instead of three; `le1`: all three slopes <= 1, the usual case, else the
+        // compare + select form).  (Unrolling the seven tiles for immediate LDS offsets was tried: 256 VGPRs + 9 spilled.)
+        auto row_tile = [&](int m, auto checked, auto fast) {
+            const f32x4 r0 = mma_tile1<FR_RP, 2>(ahi, alo, m, g4, l15, wh0, wl0, 0.f);
             const float4 iv4 = *reinterpret_cast<const float4*>(&rinv[m * 16 + g4 * 4]);     // 1 / scale of this lane's 4 rows
             const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m * 16 + g4 * 4 + r;
-                if (!checked.value || row < NF) yf[base0 + row * str0] = prelu_f(fmaf(r0[r], iv[r], bz0), a0);
+                const float z = fmaf(r0[r], iv[r], bz0);
+                if (!checked.value || row < NF) yf[base0 + row * str0] = fast.value ? prelu_mm<true>(z, a0) : prelu_f(z, a0);
             }
             if (two) {
-                const f32x4 r1 = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh1, wl1, 0.f);
+                const f32x4 r1 = mma_tile1<FR_RP, 2>(ahi, alo, m, g4, l15, wh1, wl1, 0.f);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m * 16 + g4 * 4 + r;
-                    if (!checked.value || row < NF) yf[base1 + row * VD] = prelu_f(fmaf(r1[r], iv[r], bz1), sv);
+                    const float z = fmaf(r1[r], iv[r], bz1);
+                    if (!checked.value || row < NF) yf[base1 + row * VD] = fast.value ? prelu_mm<true>(z, sv) : prelu_f(z, sv);
                 }
             }
         };
+        if (le1) {
 #pragma unroll 1
-        for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{});
-        row_tile(NF / 16, std::true_type{});
+            for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{}, std::true_type{});
+            row_tile(NF / 16, std::true_type{}, std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{}, std::false_type{});
+            row_tile(NF / 16, std::true_type{}, std::false_type{});
+        }
         QKV_STAMP(2);
         __syncthreads();
         QKV_STAMP(3);
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
         float* yq = yf + hd * YQS;
         float* yk = yf + Y_K0 + hd * YQS;
         float* yv = yf + Y_V0 + hd * DV;
-        const float* zero8 = yf + DQKP - 8;          // features 600..607 of Q head 0: always zero
+        const float* zero8 = yf + DQKP - 8;          // features 600..607 of Q head 0: always zero (16-byte aligned)
         _Float16* qrow = q + (bh * T + t) * LDQKH;
         _Float16* krow = kx + (bh * tkp + krow0 + t) * LDQKH;
         _Float16* vrow = vx + (bh * tkp + krow0 + t) * LDVH;
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
         // of the three rows out of the persistent frame loop and the kernel spills
         const int ln = lane + (fr >> 30);
         {   // Q and K together: two independent statistics chains
-            HeadLN<DQK, QKB> lq, lk;
+            HeadLN<DQK, 2 * QKB> lq, lk;
             lq.load_affine(lnq_w, lnq_b, ln);
             lk.load_affine(lnk_w, lnk_b, ln);
             const float sq1 = lq.read(yq, zero8, ln), sk1 = lk.read(yk, zero8, ln);
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
         }
         QKV_STAMP(4);
         {
-            HeadLN<DV, DV / 8> lv;
+            HeadLN<DV, DV / 4> lv;
             lv.load_affine(lnv_w, lnv_b, ln);
             const float sv1 = lv.read(yv, zero8, ln);
             const float mv = wave_sum(sv1) * (1.0f / DV);
@@ -324,7 +327,7 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float ys[NF * YP];
     __shared__ float red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
 
     f16x8 wh[2], wl[2];
     load_w<2>(w_pk, wave, lane, wh, wl);   // wave w owns output channels 16w .. 16w+15
@@ -358,17 +361,25 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
             rv[k] = *reinterpret_cast<const float4*>(&y2[fr + (long)min(tid + 256 * k, N4 - 1) * 4]);
 
         // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check
-        auto row_tile = [&](int m, auto checked) {
-            const f32x4 acc = mma_tile<FR_RP, 2>(ahi, alo, m, g4, l15, wh, wl, bz);
+        // (round 5: one accumulator chain, PReLU as max / min when the slope allows it — see k_qkv_proj_ln)
+        auto row_tile = [&](int m, auto checked, auto fast) {
+            const f32x4 acc = mma_tile1<FR_RP, 2>(ahi, alo, m, g4, l15, wh, wl, bz);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m * 16 + g4 * 4 + r;
-                if (!checked.value || row < NF) ys[row * YP + wave * 16 + l15] = prelu_f(acc[r], a);
+                if (!checked.value || row < NF)
+                    ys[row * YP + wave * 16 + l15] = fast.value ? prelu_mm<true>(acc[r], a) : prelu_f(acc[r], a);
             }
         };
+        if (a <= 1.0f) {
 #pragma unroll 1
-        for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{});
-        row_tile(NF / 16, std::true_type{});
+            for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{}, std::true_type{});
+            row_tile(NF / 16, std::true_type{}, std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int m = 0; m < NF / 16; ++m) row_tile(m, std::false_type{}, std::false_type{});
+            row_tile(NF / 16, std::true_type{}, std::false_type{});
+        }
         __syncthreads();
 
         // joint LayerNorm over all 97*64 values of the frame (flat index f*64 + c), float4 granules

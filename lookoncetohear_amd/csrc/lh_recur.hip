@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * XP_AP];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * XP_AP];
     __shared__ __attribute__((aligned(16))) float ls[2 * NS * XP_LSP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
 #if defined(XP_TRACE)
     __shared__ unsigned long long tr[128 * 4];
     const int tr_slot = blockIdx.x == 7 ? 0 : (blockIdx.x == gridDim.x / 2 + 3 ? 1 : -1);

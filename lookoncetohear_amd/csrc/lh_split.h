@@ -55,6 +55,25 @@ __device__ __forceinline__ f32x4 mma_tile(const _Float16* ahi, const _Float16* a
     return f32x4{am[0] + ac[0], am[1] + ac[1], am[2] + ac[2], am[3] + ac[3]};
 }
 
+// The same product on ONE accumulator chain (the un-rescaled split allows it): no am + ac adds in the epilogue — 4 vector
+// instructions per tile fewer, which is what counts in the VALU-bound frame kernels (two co-resident workgroups cover the
+// longer dependent MFMA chain).
+template <int RP, int KS>
+__device__ __forceinline__ f32x4 mma_tile1(const _Float16* ahi, const _Float16* alo, int m, int g4, int l15,
+                                           const f16x8 (&wh)[KS], const f16x8 (&wl)[KS], float bias) {
+    f32x4 am = f32x4{bias, bias, bias, bias};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int idx = a_slot<RP>(ks * 4 + g4, m * 16 + l15);
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
+        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], am, 0, 0, 0);      // small terms first
+        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], am, 0, 0, 0);
+        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
+    }
+    return am;
+}
+
 // weight image: [n-tile][kstep][lane][hi 8 | lo 8] fp16 (weights.py: pack_linear_f16x3)
 template <int KS>
 __device__ __forceinline__ void load_w(const _Float16* __restrict__ w_pk, int nt, int lane, f16x8 (&wh)[KS],

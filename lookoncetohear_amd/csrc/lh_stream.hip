@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float gxs[NF * IS_GP];       // input half of the gates, [step][column]
     __shared__ __attribute__((aligned(16))) float hs[2][H];              // h_{t-1} / h_t
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int frame = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* xf = x + (long)frame * NF * C;
 
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float xraw[IM_TC * IM_XP];   // un-normalised rows (residual)
     __shared__ __attribute__((aligned(16))) float gxs[IM_TC * IS_GP];    // input half of the gates, [step][column]
     __shared__ __attribute__((aligned(16))) float hs[2][H];              // h_{t-1} / h_t
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int seq = blockIdx.x, b = seq / NF, f = seq % NF;              // state row b*97 + f
     const float* xs = x + ((long)b * T * NF + f) * C;                    // step t -> + t * 97 * 64
     float* os = out + ((long)b * T * NF + f) * C;

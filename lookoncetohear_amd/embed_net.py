@@ -14,6 +14,7 @@ templated frame kernels of lh_pointwise.hip) behind the C ABI.  No CPU fallback.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -81,7 +82,6 @@ class EmbedTFGridNet(_cabi.HipHost, nn.Module):
         # axis path: k_emb_rec (input GEMM inside the recurrence, round 4) or the round-1 three-kernel form with the gate
         # pre-activations through HBM (LOOKONCE_EMB_FUSED=0; A/B runs against a -DLH_LEGACY lab build only: the product
         # library does not contain it and the call fails loudly)
-        import os
         self.fused_axis = os.environ.get("LOOKONCE_EMB_FUSED", "1") != "0"
         self.n_streams = int(os.environ.get("LOOKONCE_EMB_STREAMS", "2"))
         self._side = None
@@ -94,7 +94,17 @@ class EmbedTFGridNet(_cabi.HipHost, nn.Module):
         key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
         if key != self._pack_key:
             with torch.no_grad():
-                self._packed = pack_embedder({k: v.detach() for k, v in self.state_dict().items()}, self.n_layers)
+                sd = {k: v.detach() for k, v in self.state_dict().items()}
+                if os.environ.get("LOOKONCE_PACK_ON_HOST") == "1":
+                    # the packers are index arithmetic + fp16 splits (~6000 tiny indexing launches on the device): under
+                    # rocprofv3 --pmc that dispatch storm crashes the profiler (round 5, profiles/README.md), so the
+                    # profiling recipe packs on the host and uploads the images — same bits, one copy per tensor
+                    dev = next(iter(sd.values())).device
+                    to_dev = lambda o: (o.to(dev) if torch.is_tensor(o) else
+                                        ({k: to_dev(v) for k, v in o.items()} if isinstance(o, dict) else [to_dev(v) for v in o]))
+                    self._packed = to_dev(pack_embedder({k: v.cpu() for k, v in sd.items()}, self.n_layers))
+                else:
+                    self._packed = pack_embedder(sd, self.n_layers)
             self._pack_key = key
         return self._packed
 

@@ -436,6 +436,29 @@ def test_embedder_stages_and_embedding(fused_axis):
         net(torch.zeros(1, 3, 1280))       # wrong mic count
 
 
+def test_embedder_attention_gemms_longer_clip():
+    """136 frames (Tp = 192): the P.V product of k_gemm_nt2 then runs 6 k-steps — two turns of its three-slot B-fragment
+    ring, which the 21-frame test above (2 k-steps) never reaches; the score product (17 k-steps) does in both.  One
+    utterance, embedding against the fp64 oracle; also the pre-round-5 GEMM (lh_set_tuning(17, 0)) on the same input."""
+    from tests.hipemu.build_emu import build_emu
+    from oracle import embedder_oracle as E
+    cfg = E.ECfg(**E.EMBED_PARAMS)
+    sd = E.synthetic_state_dict(cfg, 0)
+    net = EmuEmbed(**E.EMBED_PARAMS).eval()
+    net.load_state_dict(sd, strict=True)
+    net.emu_lib = _cabi.Lib(build_emu())
+    x = synth.batch([7], 64 * 135)["mixture"]
+    ref = E.forward(cfg, sd, x, dtype=torch.float64)
+    emb = net(x)
+    assert float((emb.double() - ref).abs().max()) < 2e-5
+    net.emu_lib.call("lh_set_tuning", 17, 0)
+    try:
+        old = net(x)
+    finally:
+        net.emu_lib.call("lh_set_tuning", 17, 1)
+    assert float((old.double() - ref).abs().max()) < 2e-5 and float((old - emb).abs().max()) < 1e-5
+
+
 def test_packed_blob_is_a_sufficient_weight_source(emu_net, tmp_path):
     """`Net.from_packed`: no parameter tree, every C-ABI weight argument comes from the LHWPACK1 blob
     (include/lookonce_weights.h) — bit-equal to the module-backed run (emulated library, CPU tensors)."""
