@@ -1286,6 +1286,106 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
         }
 }
 
+// k_gemm_nt with its one defect removed and nothing else changed (both operands through LDS, two accumulator sets): the
+// straight-line / ragged kernel pair of k_gemm_nt2 instead of an exec-masked branch around every MFMA.  lh_set_tuning(17, 2).
+template <int EPI, bool RAGGED, bool ONE_CHAIN>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt3(const _Float16* __restrict__ A, const _Float16* __restrict__ Bm,
+                                                    float* __restrict__ Cm, int M, int N, int K, int lda, int ldb,
+                                                    long strideA, long strideB, long imgA, long imgB, int ldc,
+                                                    long strideC, float scale, int nbatch, int tiles_m, int tiles_n,
+                                                    int tn_begin, int Bn, int T) {
+    __shared__ __attribute__((aligned(16))) _Float16 sm[2][4][GM_IMG];      // [stage][A hi, A lo, B hi, B lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware decode: consecutive workgroup ids go round-robin over the 8 XCDs; keep a batch on one XCD
+    const int ntile = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int batch = (j / ntile) * 8 + xcd, tile = j % ntile;
+    if (batch >= nbatch) return;
+    const int m0 = (tile / tiles_n) * 128, n0 = (tn_begin + tile % tiles_n) * 128;
+    const _Float16* Ab = A + (long)batch * strideA;
+    const _Float16* Bb = Bm + (long)batch * strideB;
+
+    // staging: 128 rows x 4 k-blocks of 16 bytes per image = 512 items, 2 per thread
+    const int sr = tid >> 2, sb = tid & 3;
+    const long a_off0 = (long)min(m0 + sr, M - 1) * lda + sb * 8, a_off1 = (long)min(m0 + sr + 64, M - 1) * lda + sb * 8;
+    const long b_off0 = (long)min(n0 + sr, N - 1) * ldb + sb * 8, b_off1 = (long)min(n0 + sr + 64, N - 1) * ldb + sb * 8;
+    const int s_idx0 = (sb * GM_RP + sr) * 8, s_idx1 = (sb * GM_RP + sr + 64) * 8;
+    f16x8 st[8];
+    auto fetch = [&](int k0) {
+        st[0] = *reinterpret_cast<const f16x8*>(Ab + a_off0 + k0);        st[1] = *reinterpret_cast<const f16x8*>(Ab + a_off1 + k0);
+        st[2] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off0 + k0); st[3] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off1 + k0);
+        st[4] = *reinterpret_cast<const f16x8*>(Bb + b_off0 + k0);        st[5] = *reinterpret_cast<const f16x8*>(Bb + b_off1 + k0);
+        st[6] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off0 + k0); st[7] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off1 + k0);
+    };
+    f32x4 am[4][4], ac[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) { am[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    fetch(0);
+    const int nk = K / 32;
+    const int jn_live = __builtin_amdgcn_readfirstlane(min(4, max(0, (N - (n0 + wn * 64) + 15) / 16)));   // scalar: see k_gemm_nt2
+#pragma unroll 1
+    for (int ks = 0; ks < nk; ++ks) {
+        _Float16* buf = &sm[ks & 1][0][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx0]) = st[2 * i];
+            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx1]) = st[2 * i + 1];
+        }
+        __syncthreads();
+        if (ks + 1 < nk) fetch((ks + 1) * 32);
+        f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+            const int idx = (g4 * GM_RP + wn * 64 + jn * 16 + l15) * 8;
+            bh[jn] = *reinterpret_cast<const f16x8*>(&buf[2 * GM_IMG + idx]);
+            bl[jn] = *reinterpret_cast<const f16x8*>(&buf[3 * GM_IMG + idx]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = (g4 * GM_RP + wm * 64 + i * 16 + l15) * 8;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&buf[idx]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                if (!RAGGED || jn < jn_live) {
+                    if (ONE_CHAIN) {        // one accumulator set (64 registers fewer; the un-rescaled split needs no second chain)
+                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], am[i][jn], 0, 0, 0);
+                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], am[i][jn], 0, 0, 0);
+                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
+                    } else {
+                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
+                        ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], ac[i][jn], 0, 0, 0);
+                        ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], ac[i][jn], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // epilogue: lane holds rows g4*4 + r, column l15 of each 16 x 16 tile -> 64-byte row segments
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+            const int col = n0 + wn * 64 + jn * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + g4 * 4 + r;
+                if (row < M && col < N) {
+                    const float val = (am[i][jn][r] + ac[i][jn][r] * (1.0f / ESPLIT)) * scale;
+                    if (EPI == 0) {
+                        Cm[(long)batch * strideC + (long)row * ldc + col] = val;
+                    } else {                     // batch = h*Bn + b, row = frame, col = f*16 + v
+                        const int hd = batch / Bn, b = batch % Bn;
+                        Cm[(((long)b * T + row) * EF + (col >> 4)) * C + hd * VD + (col & 15)] = val;
+                    }
+                }
+            }
+        }
+}
+
 // Round 5 ("change the structure"): the same product with the B operand OUT of LDS.  k_gemm_nt above moves
 // both operands' hi and lo images through LDS — per CU and 32-wide k-step 64 KB of ds_read_b128 plus 64 KB of staging
 // writes (two workgroups) against 1536 cycles of matrix-pipe time: 1024 + 512 LDS cycles, i.e. the LDS pipe is as busy as
@@ -1688,9 +1788,9 @@ extern "C" int lh_probe_er_trace_read(unsigned long long* host_dst) {
 #endif
 namespace lh {
 static int g_rec_prio = 0;              // lh_set_tuning key 16: issue priority for k_emb_rec's on-chain MFMAs (0 = off)
-static int g_gemm_v = 1;                // lh_set_tuning key 17: attention GEMM variant (1 = k_gemm_nt2, 0 = k_gemm_nt)
+static int g_gemm_v = 2;                // lh_set_tuning key 17: attention GEMM variant (0 = k_gemm_nt, 1 = k_gemm_nt2, 2 = k_gemm_nt3)
 int emb_set(int key, int value) {
-    if ((key != 16 && key != 17) || value < 0 || value > 1) return LH_ERR_ARG;
+    if ((key != 16 && key != 17) || value < 0 || value > (key == 17 ? 3 : 1)) return LH_ERR_ARG;
     if (key == 16) g_rec_prio = value;
     else g_gemm_v = value;
     return LH_OK;
@@ -1762,8 +1862,16 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
     const int nb8 = (nb + 7) / 8 * 8;
     const int tm = (T + 127) / 128;
     // g_gemm_v (lh_set_tuning key 17): 1 = k_gemm_nt2 (B operand straight from global memory, round 5), 0 = k_gemm_nt (A/B)
-    if (g_gemm_v)     // scores: every column tile on the straight-line kernel (the last one wastes <= 1 sub-tile of 80)
+    if (g_gemm_v == 1)     // scores: every column tile on the straight-line kernel (the last one wastes <= 1 sub-tile of 80)
         hipLaunchKernelGGL((k_gemm_nt2<0, false>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc,
+                           T, T, EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
+                           1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T);
+    else if (g_gemm_v == 2)
+        hipLaunchKernelGGL((k_gemm_nt3<0, false, false>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc,
+                           T, T, EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
+                           1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T);
+    else if (g_gemm_v == 3)
+        hipLaunchKernelGGL((k_gemm_nt3<0, false, true>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc,
                            T, T, EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
                            1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T);
     else
@@ -1789,7 +1897,23 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
 #undef LH_SOFTMAX_REG
     }
     const int tn = (EDV + 127) / 128;
-    if (g_gemm_v) {
+    if (g_gemm_v == 2) {
+        const int tn_full = EDV / 128;
+        hipLaunchKernelGGL((k_gemm_nt3<1, false, false>), dim3(nb8 * tm * tn_full), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt,
+                           merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn_full, 0, B, T);
+        if (tn > tn_full)
+            hipLaunchKernelGGL((k_gemm_nt3<1, true, false>), dim3(nb8 * tm * (tn - tn_full)), dim3(256), 0, st, (const _Float16*)p,
+                               (const _Float16*)vt, merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L,
+                               1.0f, nb, tm, tn - tn_full, tn_full, B, T);
+    } else if (g_gemm_v == 3) {
+        const int tn_full = EDV / 128;
+        hipLaunchKernelGGL((k_gemm_nt3<1, false, true>), dim3(nb8 * tm * tn_full), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt,
+                           merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn_full, 0, B, T);
+        if (tn > tn_full)
+            hipLaunchKernelGGL((k_gemm_nt3<1, true, true>), dim3(nb8 * tm * (tn - tn_full)), dim3(256), 0, st, (const _Float16*)p,
+                               (const _Float16*)vt, merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L,
+                               1.0f, nb, tm, tn - tn_full, tn_full, B, T);
+    } else if (g_gemm_v == 1) {
         const int tn_full = EDV / 128;            // 8 full column tiles on the straight-line kernel, the ragged ninth on its own
         hipLaunchKernelGGL((k_gemm_nt2<1, false>), dim3(nb8 * tm * tn_full), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt,
                            merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn_full, 0, B, T);

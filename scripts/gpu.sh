@@ -68,6 +68,7 @@ profile)            # rocprofv3 kernel stats + PMC passes (separate runs) of the
 profile_embed)      # the same evidence set for BASELINE configs[4]: kernel stats + FETCH / WRITE / sq / sq2 passes
     cd /tmp && export TMPDIR=/tmp       # of `bench.py --mode embed`; merges an `embed` section into gpurun_out/pmc_traffic.json
     export LOOKONCE_PACK_ON_HOST=1     # the device-side weight packers' ~6000 tiny indexing launches crash rocprofv3 --pmc
+    export LOOKONCE_EMB_STREAMS=1      # one stream: every launch is a whole-batch launch (5 forwards = 5 calls of each stage)
     P="python $R/bench.py --mode embed --steps 3 --warmup 1 --no-cpu-baseline"
     timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/eprof_stats -o r1 -- $P > $R/gpurun_out/eprof_stats.log 2>&1; echo "rocprof rc=$?"
     python $R/scripts/rocpd_summary.py /tmp/eprof_stats/r1_results.db $R/gpurun_out/embed_kernel_stats.csv

@@ -437,9 +437,9 @@ def test_embedder_stages_and_embedding(fused_axis):
 
 
 def test_embedder_attention_gemms_longer_clip():
-    """136 frames (Tp = 192): the P.V product of k_gemm_nt2 then runs 6 k-steps — two turns of its three-slot B-fragment
-    ring, which the 21-frame test above (2 k-steps) never reaches; the score product (17 k-steps) does in both.  One
-    utterance, embedding against the fp64 oracle; also the pre-round-5 GEMM (lh_set_tuning(17, 0)) on the same input."""
+    """136 frames (Tp = 192): the P.V product then runs 6 k-steps — two turns of k_gemm_nt2's three-slot B-fragment ring,
+    which the 21-frame test above (2 k-steps) never reaches; the score product (17 k-steps) does in both.  One utterance,
+    embedding against the fp64 oracle, with every GEMM variant of lh_set_tuning key 17 (default: k_gemm_nt3)."""
     from tests.hipemu.build_emu import build_emu
     from oracle import embedder_oracle as E
     cfg = E.ECfg(**E.EMBED_PARAMS)
@@ -451,12 +451,14 @@ def test_embedder_attention_gemms_longer_clip():
     ref = E.forward(cfg, sd, x, dtype=torch.float64)
     emb = net(x)
     assert float((emb.double() - ref).abs().max()) < 2e-5
-    net.emu_lib.call("lh_set_tuning", 17, 0)
+    default = 2
     try:
-        old = net(x)
+        for variant in (0, 1, 3):                  # k_gemm_nt (rounds 1-4), k_gemm_nt2 (B from global), k_gemm_nt3 one chain
+            net.emu_lib.call("lh_set_tuning", 17, variant)
+            other = net(x)
+            assert float((other.double() - ref).abs().max()) < 2e-5 and float((other - emb).abs().max()) < 1e-5, variant
     finally:
-        net.emu_lib.call("lh_set_tuning", 17, 1)
-    assert float((old.double() - ref).abs().max()) < 2e-5 and float((old - emb).abs().max()) < 1e-5
+        net.emu_lib.call("lh_set_tuning", 17, default)
 
 
 def test_packed_blob_is_a_sufficient_weight_source(emu_net, tmp_path):
