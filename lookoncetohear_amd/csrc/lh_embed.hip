@@ -1191,6 +1191,7 @@ __global__ void __launch_bounds__(256) k_emb_vt(const float* __restrict__ v, _Fl
 // panel is then read from HBM once per L2 instead of once per XCD).
 constexpr int GM_RP = 130;                        // rows per 16-byte k-block plane (+2: staging writes conflict-free)
 constexpr int GM_IMG = 4 * GM_RP * 8;             // halves per (operand, hi|lo) stage image
+#if defined(LH_LEGACY)   // the GEMM as it shipped in rounds 1-4 (an exec-masked branch around every MFMA): A/B lab + emulator builds
 template <int EPI>
 __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__ A, const _Float16* __restrict__ Bm,
                                                     float* __restrict__ Cm, int M, int N, int K, int lda, int ldb,
@@ -1286,15 +1287,43 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const _Float16* __restrict__
         }
 }
 
-// k_gemm_nt with its one defect removed and nothing else changed (both operands through LDS, two accumulator sets): the
-// straight-line / ragged kernel pair of k_gemm_nt2 instead of an exec-masked branch around every MFMA.  lh_set_tuning(17, 2).
-template <int EPI, bool RAGGED, bool ONE_CHAIN>
-__global__ void __launch_bounds__(256, 2) k_gemm_nt3(const _Float16* __restrict__ A, const _Float16* __restrict__ Bm,
-                                                    float* __restrict__ Cm, int M, int N, int K, int lda, int ldb,
-                                                    long strideA, long strideB, long imgA, long imgB, int ldc,
-                                                    long strideC, float scale, int nbatch, int tiles_m, int tiles_n,
-                                                    int tn_begin, int Bn, int T) {
-    __shared__ __attribute__((aligned(16))) _Float16 sm[2][4][GM_IMG];      // [stage][A hi, A lo, B hi, B lo]
+#endif  // LH_LEGACY
+
+// Round 5: k_gemm_nt3 = the same tiling with two defects removed (read off the ISA).
+//  (1) `jn_live` (how many 16-column sub-tiles of the wave hold a live column) is wave-uniform but derived from threadIdx, so
+//      the compiler took it for divergent and put EVERY MFMA of the loop into its own exec-masked branch (s_and_saveexec +
+//      s_cbranch around each of the 48; 137 s_and_saveexec in the kernel).  Now: RAGGED = false computes every sub-tile
+//      (straight-line MFMAs; columns >= N run on a clamped duplicate row and are not stored), RAGGED = true skips dead
+//      sub-tiles with SCALAR branches (`jn_live` through v_readfirstlane).  Two kernels, not two paths in one: the register
+//      allocator sees one loop each.  The workgroup's column tile is tn_begin + (tile % tiles_n): the P.V product (N = 1040 =
+//      8 x 128 + 16) runs its 8 full column tiles on the straight-line kernel and the ninth on the ragged one; the score
+//      product runs every column tile straight-line (its last one wastes <= 1 sub-tile of 80).
+//  (2) ONE accumulator set per tile (the un-rescaled split needs no second chain; the three products of a tile are issued
+//      in the order lo*hi, hi*lo, hi*hi): 166 VGPRs instead of 230.
+// Measured (profiles/r05c_gemm_variants.txt, attention block of the B = 64 forward, same box): 26.5 ms (rounds 1-4 kernel) ->
+// 26.2 (1) -> 25.85 (1 + 2): the exec-masked branches were NOT what holds the GEMMs at 0.34 of the matrix core's rate — LDS
+// traffic is (both operands' hi and lo images: per CU and k-step 128 KB of ds_read_b128 + 64 KB of staging writes against
+// 1536 cycles of matrix-pipe time).  The obvious alternative — B fragments straight from global memory (K-contiguous rows:
+// a lane's fragment is 16 contiguous bytes), three-slot register ring, only A through LDS — was built and measured SLOWER:
+// 31.7 ms (profiles/r05b_gemm_direct_b_negative.txt; 8 KB of 64-byte-segment loads per wave and k-step through the
+// texture path cost more than the LDS round trip they replace); removed.
+// MODE (lh_set_tuning key 17, A/B): 1 = staging registers ONE k-step ahead, double-buffered LDS, two workgroups per CU (the
+// rounds 1-4 pipeline); 2 = staging registers TWO k-steps ahead (the loop unrolled by two: the loads of k-step ks + 2 are
+// issued while ks is computed and land in a second register set), 3 = ONE LDS stage, two barriers per k-step, THREE
+// workgroups per CU (166 VGPRs fit three waves per SIMD; 33 KB of LDS each).
+template <int EPI, bool RAGGED, int MODE, bool EXTRA = false>
+__device__ __forceinline__ void gemm_nt3_body(const _Float16* __restrict__ A, const _Float16* __restrict__ Bm,
+                                              float* __restrict__ Cm, int M, int N, int K, int lda, int ldb, long strideA,
+                                              long strideB, long imgA, long imgB, int ldc, long strideC, float scale, int nbatch,
+                                              int tiles_m, int tiles_n, int tn_begin, int Bn, int T) {
+    constexpr int NSTAGE = MODE == 3 ? 1 : 2;
+    // EXTRA: the column tile is 128 + 16 wide (the P.V product's N = 1040 = 7 x 128 + 144: its last 16 columns ride on column
+    // tile 7 instead of a ninth, ragged tile that re-read all of P for 1.5 % of the columns — 0.39 ms per call).  The 17th
+    // sub-tile is split by ROWS so that every wave gets the same extra work: wave (wm, wn) computes rows wm*64 + (2 wn + ii)*16,
+    // ii = 0, 1, of it (6 MFMAs per k-step on A fragments it has loaded anyway).
+    constexpr int RPB = EXTRA ? GM_RP + 16 : GM_RP, IMGB = 4 * RPB * 8;
+    constexpr int STAGE_HALVES = 2 * GM_IMG + 2 * IMGB;
+    __shared__ __attribute__((aligned(16))) _Float16 sm[NSTAGE][STAGE_HALVES];   // [stage][A hi | A lo | B hi | B lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware decode: consecutive workgroup ids go round-robin over the 8 XCDs; keep a batch on one XCD
@@ -1311,191 +1340,102 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt3(const _Float16* __restrict_
     const long a_off0 = (long)min(m0 + sr, M - 1) * lda + sb * 8, a_off1 = (long)min(m0 + sr + 64, M - 1) * lda + sb * 8;
     const long b_off0 = (long)min(n0 + sr, N - 1) * ldb + sb * 8, b_off1 = (long)min(n0 + sr + 64, N - 1) * ldb + sb * 8;
     const int s_idx0 = (sb * GM_RP + sr) * 8, s_idx1 = (sb * GM_RP + sr + 64) * 8;
-    f16x8 st[8];
-    auto fetch = [&](int k0) {
-        st[0] = *reinterpret_cast<const f16x8*>(Ab + a_off0 + k0);        st[1] = *reinterpret_cast<const f16x8*>(Ab + a_off1 + k0);
-        st[2] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off0 + k0); st[3] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off1 + k0);
-        st[4] = *reinterpret_cast<const f16x8*>(Bb + b_off0 + k0);        st[5] = *reinterpret_cast<const f16x8*>(Bb + b_off1 + k0);
-        st[6] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off0 + k0); st[7] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off1 + k0);
-    };
-    f32x4 am[4][4], ac[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) { am[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    fetch(0);
-    const int nk = K / 32;
-    const int jn_live = __builtin_amdgcn_readfirstlane(min(4, max(0, (N - (n0 + wn * 64) + 15) / 16)));   // scalar: see k_gemm_nt2
-#pragma unroll 1
-    for (int ks = 0; ks < nk; ++ks) {
-        _Float16* buf = &sm[ks & 1][0][0];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx0]) = st[2 * i];
-            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx1]) = st[2 * i + 1];
-        }
-        __syncthreads();
-        if (ks + 1 < nk) fetch((ks + 1) * 32);
-        f16x8 bh[4], bl[4];
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-            const int idx = (g4 * GM_RP + wn * 64 + jn * 16 + l15) * 8;
-            bh[jn] = *reinterpret_cast<const f16x8*>(&buf[2 * GM_IMG + idx]);
-            bl[jn] = *reinterpret_cast<const f16x8*>(&buf[3 * GM_IMG + idx]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = (g4 * GM_RP + wm * 64 + i * 16 + l15) * 8;
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(&buf[idx]);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn) {
-                if (!RAGGED || jn < jn_live) {
-                    if (ONE_CHAIN) {        // one accumulator set (64 registers fewer; the un-rescaled split needs no second chain)
-                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], am[i][jn], 0, 0, 0);
-                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], am[i][jn], 0, 0, 0);
-                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
-                    } else {
-                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[jn], am[i][jn], 0, 0, 0);
-                        ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[jn], ac[i][jn], 0, 0, 0);
-                        ac[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[jn], ac[i][jn], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-    // epilogue: lane holds rows g4*4 + r, column l15 of each 16 x 16 tile -> 64-byte row segments
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-            const int col = n0 + wn * 64 + jn * 16 + l15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + g4 * 4 + r;
-                if (row < M && col < N) {
-                    const float val = (am[i][jn][r] + ac[i][jn][r] * (1.0f / ESPLIT)) * scale;
-                    if (EPI == 0) {
-                        Cm[(long)batch * strideC + (long)row * ldc + col] = val;
-                    } else {                     // batch = h*Bn + b, row = frame, col = f*16 + v
-                        const int hd = batch / Bn, b = batch % Bn;
-                        Cm[(((long)b * T + row) * EF + (col >> 4)) * C + hd * VD + (col & 15)] = val;
-                    }
-                }
-            }
-        }
-}
-
-// Round 5 ("change the structure"): the same product with the B operand OUT of LDS.  k_gemm_nt above moves
-// both operands' hi and lo images through LDS — per CU and 32-wide k-step 64 KB of ds_read_b128 plus 64 KB of staging
-// writes (two workgroups) against 1536 cycles of matrix-pipe time: 1024 + 512 LDS cycles, i.e. the LDS pipe is as busy as
-// the matrix pipe and every hiccup of one stalls the other (0.6 - 0.78 PFLOP/s executed, 0.34 of what the matrix core
-// sustains).  Both operands are K-contiguous rows (NT), so a lane's B fragment — row n0 + l15, halves 32 ks + 8 g4 .. + 7 —
-// is 16 contiguous bytes of global memory: B fragments are loaded straight into registers, TWO k-steps ahead (a three-slot
-// register ring; the two waves that share a column block hit the same lines in L1 / L2), and only A goes through LDS
-// (global -> registers -> double-buffered LDS as before).  LDS traffic per MFMA halves, the staging of a stage is 4
-// ds_write_b128 per thread instead of 8, and one accumulator set per tile (the un-rescaled split needs no second chain:
-// the three products of a tile are issued 16 MFMAs apart) leaves the registers for the ring.
-// RAGGED = false: every 16-column sub-tile is computed (straight-line MFMAs; columns >= N run on a clamped duplicate row and
-// are not stored); RAGGED = true: sub-tiles without a live column are skipped with SCALAR branches (`jn_live` through
-// v_readfirstlane: derived from threadIdx the compiler took it for divergent and wrapped every MFMA of k_gemm_nt in its own
-// exec-masked branch).  Two kernels, not two paths in one: the register allocator sees one loop each.  The workgroup's
-// column tile is tn_begin + (tile % tiles_n): the P.V product (N = 1040 = 8 x 128 + 16) runs its 8 full column tiles on
-// the straight-line kernel and the ninth on the ragged one.
-template <int EPI, bool RAGGED>
-__global__ void __launch_bounds__(256, 2) k_gemm_nt2(const _Float16* __restrict__ A, const _Float16* __restrict__ Bm,
-                                                     float* __restrict__ Cm, int M, int N, int K, int lda, int ldb,
-                                                     long strideA, long strideB, long imgA, long imgB, int ldc,
-                                                     long strideC, float scale, int nbatch, int tiles_m, int tiles_n,
-                                                     int tn_begin, int Bn, int T) {
-    __shared__ __attribute__((aligned(16))) _Float16 sm[2][2][GM_IMG];      // [stage][A hi, A lo]
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntile = tiles_m * tiles_n;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int batch = (j / ntile) * 8 + xcd, tile = j % ntile;
-    if (batch >= nbatch) return;
-    const int m0 = (tile / tiles_n) * 128, n0 = (tn_begin + tile % tiles_n) * 128;
-    const _Float16* Ab = A + (long)batch * strideA;
-    const _Float16* Bb = Bm + (long)batch * strideB;
-
-    // A staging: 128 rows x 4 k-blocks of 16 bytes per image = 512 items, 2 per thread and image
-    const int sr = tid >> 2, sb = tid & 3;
-    const long a_off0 = (long)min(m0 + sr, M - 1) * lda + sb * 8, a_off1 = (long)min(m0 + sr + 64, M - 1) * lda + sb * 8;
-    const int s_idx0 = (sb * GM_RP + sr) * 8, s_idx1 = (sb * GM_RP + sr + 64) * 8;
-    f16x8 st[4];
-    auto fetch_a = [&](int k0) {
-        st[0] = *reinterpret_cast<const f16x8*>(Ab + a_off0 + k0);        st[1] = *reinterpret_cast<const f16x8*>(Ab + a_off1 + k0);
-        st[2] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off0 + k0); st[3] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off1 + k0);
-    };
-    // B fragments of this wave's four 16-column sub-tiles, straight from global memory (rows clamped: dead columns of the
-    // last tile compute on a duplicate row and are never stored)
-    const int jn_live = __builtin_amdgcn_readfirstlane(min(4, max(0, (N - (n0 + wn * 64) + 15) / 16)));   // sub-tiles with any column < N
-    int b_off[4];                            // halves from the batch's panel (a panel is < 2^31 halves)
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn) b_off[jn] = min(n0 + wn * 64 + jn * 16 + l15, N - 1) * ldb + g4 * 8;
-    f16x8 bh[3][4], bl[3][4];
-    auto fetch_b = [&](auto slot_, int k0) {
-        constexpr int slot = decltype(slot_)::value;
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-            bh[slot][jn] = *reinterpret_cast<const f16x8*>(Bb + b_off[jn] + k0);
-            bl[slot][jn] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off[jn] + k0);
+    const int sb_idx0 = (sb * RPB + sr) * 8, sb_idx1 = (sb * RPB + sr + 64) * 8;
+    // EXTRA: B rows 128 .. 143 of the tile = 64 more 16-byte items per image: threads 0 .. 63 (wave 0), one hi + one lo each
+    const long bx_off = (long)min(n0 + 128 + sr, N - 1) * ldb + sb * 8;
+    const int sbx_idx = (sb * RPB + 128 + sr) * 8;
+    constexpr int NSET = MODE == 2 ? 2 : 1;
+    f16x8 st[NSET][8], stx[NSET][2];
+    auto fetch = [&](auto set_, int k0) {
+        constexpr int q = decltype(set_)::value;
+        st[q][0] = *reinterpret_cast<const f16x8*>(Ab + a_off0 + k0);        st[q][1] = *reinterpret_cast<const f16x8*>(Ab + a_off1 + k0);
+        st[q][2] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off0 + k0); st[q][3] = *reinterpret_cast<const f16x8*>(Ab + imgA + a_off1 + k0);
+        st[q][4] = *reinterpret_cast<const f16x8*>(Bb + b_off0 + k0);        st[q][5] = *reinterpret_cast<const f16x8*>(Bb + b_off1 + k0);
+        st[q][6] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off0 + k0); st[q][7] = *reinterpret_cast<const f16x8*>(Bb + imgB + b_off1 + k0);
+        if (EXTRA && wave == 0) {
+            stx[q][0] = *reinterpret_cast<const f16x8*>(Bb + bx_off + k0);
+            stx[q][1] = *reinterpret_cast<const f16x8*>(Bb + imgB + bx_off + k0);
         }
     };
+    f32x4 amx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 am[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) am[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = K / 32;
-    fetch_a(0);
-    fetch_b(std::integral_constant<int, 0>{}, 0);
-    if (nk > 1) fetch_b(std::integral_constant<int, 1>{}, 32);
+    const int jn_live = __builtin_amdgcn_readfirstlane(min(4, max(0, (N - (n0 + wn * 64) + 15) / 16)));   // scalar, see above
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NSET - 1>;
 
-    auto stage = [&](int ks, auto slot_) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slot_)::value;
-        constexpr bool FULL = !RAGGED;
-        _Float16* buf = &sm[ks & 1][0][0];
+    // one k-step: staged registers of set q -> LDS, barrier, refill the set with k-step ks + NSET, fragments + 48 MFMAs
+    auto kstep = [&](int ks, auto set_) __attribute__((always_inline)) {
+        constexpr int q = decltype(set_)::value;
+        _Float16* buf = &sm[NSTAGE == 2 ? (ks & 1) : 0][0];
+        _Float16* bufb = buf + 2 * GM_IMG;                        // B hi image, B lo image IMGB halves behind it
+        if (NSTAGE == 1) __syncthreads();                         // every wave has read the previous k-step's fragments
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx0]) = st[2 * i];
-            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx1]) = st[2 * i + 1];
+            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx0]) = st[q][2 * i];
+            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx1]) = st[q][2 * i + 1];
+            *reinterpret_cast<f16x8*>(&bufb[i * IMGB + sb_idx0]) = st[q][4 + 2 * i];
+            *reinterpret_cast<f16x8*>(&bufb[i * IMGB + sb_idx1]) = st[q][4 + 2 * i + 1];
+        }
+        if (EXTRA && wave == 0) {
+            *reinterpret_cast<f16x8*>(&bufb[sbx_idx]) = stx[q][0];
+            *reinterpret_cast<f16x8*>(&bufb[IMGB + sbx_idx]) = stx[q][1];
         }
         __syncthreads();
-        if (ks + 1 < nk) fetch_a((ks + 1) * 32);
-        if (ks + 2 < nk) fetch_b(std::integral_constant<int, (slot + 2) % 3>{}, (ks + 2) * 32);
-        // two row-tile pairs (A fragments of a pair: 16 registers); small products first; the three products of one tile
-        // are 8 MFMAs apart (no back-to-back dependent MFMAs)
+        fetch(set_, min(ks + NSET, nk - 1) * 32);       // unconditional (the tail re-fetches the last k-step): a straight-line body keeps
+                                                          // the compiler's vmcnt bookkeeping exact — behind a branch it drained every load
+        __builtin_amdgcn_sched_barrier(0);                // the loads go out HERE (the scheduler otherwise sinks them below the MFMAs
+                                                          // to recycle the staging registers as fragment registers: no prefetch left)
+        f16x8 bh[4], bl[4];
 #pragma unroll
-        for (int ip = 0; ip < 2; ++ip) {
-            f16x8 ah[2], al[2];
+        for (int jn = 0; jn < 4; ++jn) {
+            const int idx = (g4 * RPB + wn * 64 + jn * 16 + l15) * 8;
+            bh[jn] = *reinterpret_cast<const f16x8*>(&bufb[idx]);
+            bl[jn] = *reinterpret_cast<const f16x8*>(&bufb[IMGB + idx]);
+        }
+        f16x8 bxh, bxl;
+        if (EXTRA) {
+            const int idx = (g4 * RPB + 128 + l15) * 8;
+            bxh = *reinterpret_cast<const f16x8*>(&bufb[idx]);
+            bxl = *reinterpret_cast<const f16x8*>(&bufb[IMGB + idx]);
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = (g4 * GM_RP + wm * 64 + (2 * ip + i) * 16 + l15) * 8;
-                ah[i] = *reinterpret_cast<const f16x8*>(&buf[idx]);
-                al[i] = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int idx = (g4 * GM_RP + wm * 64 + i * 16 + l15) * 8;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&buf[idx]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
+            // small terms first; the three products of one tile are four MFMAs apart (no back-to-back dependent MFMAs)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int jn = 0; jn < 4; ++jn)
+                    if (!RAGGED || jn < jn_live)
+                        am[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? al : ah, p == 1 ? bl[jn] : bh[jn], am[i][jn], 0, 0, 0);
+            if (EXTRA && (i >> 1) == wn) {                        // (scalar branch: wn comes from the scalar wave index)
 #pragma unroll
-                    for (int jn = 0; jn < 4; ++jn)
-                        if (FULL || jn < jn_live)
-                            am[2 * ip + i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                p == 0 ? al[i] : ah[i], p == 1 ? bl[slot][jn] : bh[slot][jn], am[2 * ip + i][jn], 0, 0, 0);
+                for (int p = 0; p < 3; ++p)
+                    amx[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? al : ah, p == 1 ? bxl : bxh, amx[i & 1], 0, 0, 0);
+            }
         }
     };
-    int ks = 0;
+    fetch(S0{}, 0);
+    if (NSET == 2) fetch(S1{}, min(1, nk - 1) * 32);          // (unconditional, like the refills)
+    if (NSET == 2) {
+        int ks = 0;
 #pragma unroll 1
-    for (; ks + 3 <= nk; ks += 3) {
-        stage(ks, std::integral_constant<int, 0>{});
-        stage(ks + 1, std::integral_constant<int, 1>{});
-        stage(ks + 2, std::integral_constant<int, 2>{});
+        for (; ks + 2 <= nk; ks += 2) {
+            kstep(ks, S0{});
+            kstep(ks + 1, S1{});
+        }
+        if (ks < nk) kstep(ks, S0{});
+    } else {
+#pragma unroll 1
+        for (int ks = 0; ks < nk; ++ks) kstep(ks, S0{});
     }
-    if (ks < nk) stage(ks, std::integral_constant<int, 0>{});
-    if (ks + 1 < nk) stage(ks + 1, std::integral_constant<int, 1>{});
     // epilogue: lane holds rows g4*4 + r, column l15 of each 16 x 16 tile -> 64-byte row segments
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1516,7 +1456,38 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt2(const _Float16* __restrict_
                 }
             }
         }
+    if (EXTRA) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int col = n0 + 128 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + (2 * wn + ii) * 16 + g4 * 4 + r;
+                if (row < M && col < N) {
+                    const float val = amx[ii][r] * scale;
+                    if (EPI == 0) {
+                        Cm[(long)batch * strideC + (long)row * ldc + col] = val;
+                    } else {
+                        const int hd = batch / Bn, b = batch % Bn;
+                        Cm[(((long)b * T + row) * EF + (col >> 4)) * C + hd * VD + (col & 15)] = val;
+                    }
+                }
+            }
+        }
+    }
 }
+#define LH_GEMM_ARGS const _Float16* __restrict__ A, const _Float16* __restrict__ Bm, float* __restrict__ Cm, int M, int N, int K, \
+    int lda, int ldb, long strideA, long strideB, long imgA, long imgB, int ldc, long strideC, float scale, int nbatch,   \
+    int tiles_m, int tiles_n, int tn_begin, int Bn, int T
+#define LH_GEMM_PASS A, Bm, Cm, M, N, K, lda, ldb, strideA, strideB, imgA, imgB, ldc, strideC, scale, nbatch, tiles_m, tiles_n, tn_begin, Bn, T
+template <int EPI, bool RAGGED, int MODE>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt3(LH_GEMM_ARGS) { gemm_nt3_body<EPI, RAGGED, MODE>(LH_GEMM_PASS); }
+template <int EPI, bool RAGGED>
+__global__ void __launch_bounds__(256, 3) k_gemm_nt3_occ3(LH_GEMM_ARGS) { gemm_nt3_body<EPI, RAGGED, 3>(LH_GEMM_PASS); }
+// the 128 + 16 column tile: ~190 VGPRs (two more accumulator tiles, the 17th sub-tile's fragments and staging) = two
+// workgroups per CU; one column tile in eight runs on it
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt3_wide(LH_GEMM_ARGS) { gemm_nt3_body<EPI, false, 3, true>(LH_GEMM_PASS); }
 
 // row softmax of the (already scaled) scores: one wave per row; P as fp16 hi/lo, keys zero-padded to Tp
 __global__ void __launch_bounds__(256) k_emb_softmax(const float* __restrict__ sc, _Float16* __restrict__ p, long rows, int T,
@@ -1788,9 +1759,12 @@ extern "C" int lh_probe_er_trace_read(unsigned long long* host_dst) {
 #endif
 namespace lh {
 static int g_rec_prio = 0;              // lh_set_tuning key 16: issue priority for k_emb_rec's on-chain MFMAs (0 = off)
-static int g_gemm_v = 2;                // lh_set_tuning key 17: attention GEMM variant (0 = k_gemm_nt, 1 = k_gemm_nt2, 2 = k_gemm_nt3)
+static int g_gemm_v = 3;                // lh_set_tuning key 17: k_gemm_nt3 pipeline 1 / 2 / 3 (see gemm_nt3_body); 0 = the rounds 1-4 k_gemm_nt (-DLH_LEGACY builds only)
 int emb_set(int key, int value) {
     if ((key != 16 && key != 17) || value < 0 || value > (key == 17 ? 3 : 1)) return LH_ERR_ARG;
+#if !defined(LH_LEGACY)
+    if (key == 17 && value == 0) return LH_ERR_UNSUPPORTED;
+#endif
     if (key == 16) g_rec_prio = value;
     else g_gemm_v = value;
     return LH_OK;
@@ -1861,23 +1835,20 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
     hipLaunchKernelGGL(k_emb_vt, dim3(Tp / 64, (EDV + 63) / 64, nb), dim3(256), 0, st, v, (_Float16*)vt, T, Tp, img_vt);
     const int nb8 = (nb + 7) / 8 * 8;
     const int tm = (T + 127) / 128;
-    // g_gemm_v (lh_set_tuning key 17): 1 = k_gemm_nt2 (B operand straight from global memory, round 5), 0 = k_gemm_nt (A/B)
-    if (g_gemm_v == 1)     // scores: every column tile on the straight-line kernel (the last one wastes <= 1 sub-tile of 80)
-        hipLaunchKernelGGL((k_gemm_nt2<0, false>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc,
-                           T, T, EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
-                           1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T);
-    else if (g_gemm_v == 2)
-        hipLaunchKernelGGL((k_gemm_nt3<0, false, false>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc,
-                           T, T, EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
-                           1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T);
-    else if (g_gemm_v == 3)
-        hipLaunchKernelGGL((k_gemm_nt3<0, false, true>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc,
-                           T, T, EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
-                           1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T);
+#if defined(LH_LEGACY)
+    if (g_gemm_v == 0)        // lab builds: the rounds 1-4 kernel (lh_set_tuning(17, 0))
+        hipLaunchKernelGGL((k_gemm_nt<0>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc, T, T,
+                           EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
+                           1.0f / sqrtf((float)EDQK), nb, tm, tm, B, T);
     else
-    hipLaunchKernelGGL((k_gemm_nt<0>), dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc, T, T,
-                       EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp,
-                       1.0f / sqrtf((float)EDQK), nb, tm, tm, B, T);
+#endif
+    // scores: every column tile on the straight-line kernel (the last one wastes <= 1 sub-tile of 80)
+#define LH_QK_LAUNCH(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc, T, T, \
+    EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp, 1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T)
+    if (g_gemm_v == 3) LH_QK_LAUNCH((k_gemm_nt3_occ3<0, false>));
+    else if (g_gemm_v == 2) LH_QK_LAUNCH((k_gemm_nt3<0, false, 2>));
+    else LH_QK_LAUNCH((k_gemm_nt3<0, false, 1>));
+#undef LH_QK_LAUNCH
     const long rows = (long)nb * T;
     {
         const dim3 sg((unsigned)((rows + 3) / 4)), sb(256);
@@ -1897,33 +1868,27 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
 #undef LH_SOFTMAX_REG
     }
     const int tn = (EDV + 127) / 128;
-    if (g_gemm_v == 2) {
-        const int tn_full = EDV / 128;
-        hipLaunchKernelGGL((k_gemm_nt3<1, false, false>), dim3(nb8 * tm * tn_full), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt,
-                           merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn_full, 0, B, T);
-        if (tn > tn_full)
-            hipLaunchKernelGGL((k_gemm_nt3<1, true, false>), dim3(nb8 * tm * (tn - tn_full)), dim3(256), 0, st, (const _Float16*)p,
-                               (const _Float16*)vt, merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L,
-                               1.0f, nb, tm, tn - tn_full, tn_full, B, T);
-    } else if (g_gemm_v == 3) {
-        const int tn_full = EDV / 128;
-        hipLaunchKernelGGL((k_gemm_nt3<1, false, true>), dim3(nb8 * tm * tn_full), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt,
-                           merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn_full, 0, B, T);
-        if (tn > tn_full)
-            hipLaunchKernelGGL((k_gemm_nt3<1, true, true>), dim3(nb8 * tm * (tn - tn_full)), dim3(256), 0, st, (const _Float16*)p,
-                               (const _Float16*)vt, merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L,
-                               1.0f, nb, tm, tn - tn_full, tn_full, B, T);
-    } else if (g_gemm_v == 1) {
+#if defined(LH_LEGACY)
+    if (g_gemm_v == 0)
+        hipLaunchKernelGGL((k_gemm_nt<1>), dim3(nb8 * tm * tn), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt, merged, T,
+                           EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn, B, T);
+    else
+#endif
+    {
         const int tn_full = EDV / 128;            // 8 full column tiles on the straight-line kernel, the ragged ninth on its own
-        hipLaunchKernelGGL((k_gemm_nt2<1, false>), dim3(nb8 * tm * tn_full), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt,
-                           merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn_full, 0, B, T);
-        if (tn > tn_full)
-            hipLaunchKernelGGL((k_gemm_nt2<1, true>), dim3(nb8 * tm * (tn - tn_full)), dim3(256), 0, st, (const _Float16*)p,
-                               (const _Float16*)vt, merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L,
-                               1.0f, nb, tm, tn - tn_full, tn_full, B, T);
-    } else
-    hipLaunchKernelGGL((k_gemm_nt<1>), dim3(nb8 * tm * tn), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt, merged, T,
-                       EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, tn, B, T);
+#define LH_PV_LAUNCH(KERNEL, NT, TB) hipLaunchKernelGGL(KERNEL, dim3(nb8 * tm * (NT)), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt, \
+    merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, (NT), (TB), B, T)
+        if (g_gemm_v == 3 && EDV % 128 == 16 && tn_full >= 1) {
+            // default: three workgroups per CU; the 16 columns behind the last full tile ride on it (EXTRA) — no ragged launch
+            if (tn_full > 1) LH_PV_LAUNCH((k_gemm_nt3_occ3<1, false>), tn_full - 1, 0);
+            LH_PV_LAUNCH((k_gemm_nt3_wide<1>), 1, tn_full - 1);
+        } else {
+            if (g_gemm_v == 2) LH_PV_LAUNCH((k_gemm_nt3<1, false, 2>), tn_full, 0);
+            else LH_PV_LAUNCH((k_gemm_nt3<1, false, 1>), tn_full, 0);
+            if (tn > tn_full) LH_PV_LAUNCH((k_gemm_nt3<1, true, 1>), tn - tn_full, tn_full);
+        }
+#undef LH_PV_LAUNCH
+    }
     hipLaunchKernelGGL(k_emb_proj, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, st, merged, (const _Float16*)wproj_pk,
                        bproj, slope_p, lnp_w, lnp_b, y2, out, (_Float16*)xsplit_next, nframes);
     return check_launch();

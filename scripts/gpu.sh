@@ -62,7 +62,7 @@ profile)            # rocprofv3 kernel stats + PMC passes (separate runs) of the
     python $R/scripts/rocpd_summary.py /tmp/prof_sq/r1_results.db $R/gpurun_out/pmc_sq.csv --pmc
     timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM -d /tmp/prof_sq2 -o r1 -- $P > $R/gpurun_out/prof_sq2.log 2>&1; echo "rocprof sq2 rc=$?"
     python $R/scripts/rocpd_summary.py /tmp/prof_sq2/r1_results.db $R/gpurun_out/pmc_sq2.csv --pmc
-    python $R/scripts/make_pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv 32 $R/gpurun_out/pmc_traffic.json $R/gpurun_out/pmc_sq.csv $R/gpurun_out/pmc_sq2.csv
+    python $R/scripts/make_pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv 32 $R/gpurun_out/pmc_traffic.json $R/gpurun_out/pmc_sq.csv $R/gpurun_out/pmc_sq2.csv $R/gpurun_out/kernel_stats.csv
     cd $R
     head -40 gpurun_out/kernel_stats.csv; head -60 gpurun_out/pmc_traffic.json ;;
 profile_embed)      # the same evidence set for BASELINE configs[4]: kernel stats + FETCH / WRITE / sq / sq2 passes

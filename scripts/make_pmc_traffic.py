@@ -34,9 +34,24 @@ def load_counters(path):
     return out
 
 
-def main(fetch_csv, write_csv, batch, out_json, sq_csv=None, sq2_csv=None):
+def kernel_times(stats_csv):
+    """first table of rocpd_summary's kernel stats (rocprofv3 --kernel-trace --stats): kernel -> (calls, avg_us)"""
+    out = {}
+    for row in csv.reader(open(stats_csv)):
+        if not row:
+            break
+        if len(row) == 5 and row[0] != "kernel" and not row[0].startswith("#"):
+            try:
+                out[row[0]] = (int(row[1]), float(row[3]))
+            except ValueError:
+                break
+    return out
+
+
+def main(fetch_csv, write_csv, batch, out_json, sq_csv=None, sq2_csv=None, stats_csv=None):
     import os
     B = int(batch)
+    tm = kernel_times(stats_csv) if stats_csv and os.path.exists(stats_csv) else {}
     fe, wr = load(fetch_csv), load(write_csv)
     sq = {}
     for path in (sq_csv, sq2_csv):
@@ -74,6 +89,8 @@ def main(fetch_csv, write_csv, batch, out_json, sq_csv=None, sq2_csv=None):
             "algorithmic_bytes_per_launch": alg,
         }
         kernels[call]["ratio_to_algorithmic"] = kernels[call]["hbm_bytes_per_launch"] / alg
+        if f[0][0][0] in tm:        # the same launch as rocprofv3's tracer times it (every dispatch separated: longer than back to back)
+            kernels[call]["rocprof_avg_launch_us"] = tm[f[0][0][0]][1]
         c = sq.get(f[0][0])
         if c and c.get("GRBM_GUI_ACTIVE"):
             # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCCs (6.4e6 for a 0.41 ms launch at ~1.9 GHz); 1024 SIMDs per chip
@@ -96,4 +113,4 @@ def main(fetch_csv, write_csv, batch, out_json, sq_csv=None, sq2_csv=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:7])
+    main(*sys.argv[1:8])

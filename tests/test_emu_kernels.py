@@ -437,9 +437,9 @@ def test_embedder_stages_and_embedding(fused_axis):
 
 
 def test_embedder_attention_gemms_longer_clip():
-    """136 frames (Tp = 192): the P.V product then runs 6 k-steps — two turns of k_gemm_nt2's three-slot B-fragment ring,
-    which the 21-frame test above (2 k-steps) never reaches; the score product (17 k-steps) does in both.  One utterance,
-    embedding against the fp64 oracle, with every GEMM variant of lh_set_tuning key 17 (default: k_gemm_nt3)."""
+    """136 frames (Tp = 192, 6 k-steps in the P.V product, two row tiles; the 21-frame test above has one tile and 2 k-steps).
+    One utterance,
+    embedding against the fp64 oracle, with k_gemm_nt3 (default) and the superseded k_gemm_nt (lh_set_tuning(17, 0))."""
     from tests.hipemu.build_emu import build_emu
     from oracle import embedder_oracle as E
     cfg = E.ECfg(**E.EMBED_PARAMS)
@@ -451,14 +451,13 @@ def test_embedder_attention_gemms_longer_clip():
     ref = E.forward(cfg, sd, x, dtype=torch.float64)
     emb = net(x)
     assert float((emb.double() - ref).abs().max()) < 2e-5
-    default = 2
     try:
-        for variant in (0, 1, 3):                  # k_gemm_nt (rounds 1-4), k_gemm_nt2 (B from global), k_gemm_nt3 one chain
+        for variant in (0, 1, 2):      # 0: the rounds 1-4 GEMM (-DLH_LEGACY builds like the emulator's); 1, 2: k_gemm_nt3's other pipelines
             net.emu_lib.call("lh_set_tuning", 17, variant)
             other = net(x)
             assert float((other.double() - ref).abs().max()) < 2e-5 and float((other - emb).abs().max()) < 1e-5, variant
     finally:
-        net.emu_lib.call("lh_set_tuning", 17, default)
+        net.emu_lib.call("lh_set_tuning", 17, 3)
 
 
 def test_packed_blob_is_a_sufficient_weight_source(emu_net, tmp_path):
