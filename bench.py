@@ -412,7 +412,7 @@ def bench_embed(args, dev, rank, world, dist):
     from lookoncetohear_amd import synth
     from lookoncetohear_amd.embed_net import EmbedTFGridNet
     from lookoncetohear_amd import config
-    B = 64 if args.batch == 32 else args.batch
+    B = args.embed_batch if args.batch == 32 else args.batch
     net = EmbedTFGridNet(**config.EMBED_PARAMS).eval()
     net.load_state_dict(config.embedder_weights(0), strict=True)
     net = net.to(dev)
@@ -770,6 +770,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE configs[2] = 32)")
+    ap.add_argument("--embed-batch", type=int, default=64, help="--mode embed: enrollments per GPU (BASELINE configs[4] = 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="skip the 2 s package-power leg (N = 1 only)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="gloo / host-tensor dry run of the N>1 plumbing (no GPU, no model)")
