@@ -1480,8 +1480,10 @@ __device__ __forceinline__ void gemm_nt3_body(const _Float16* __restrict__ A, co
     int lda, int ldb, long strideA, long strideB, long imgA, long imgB, int ldc, long strideC, float scale, int nbatch,   \
     int tiles_m, int tiles_n, int tn_begin, int Bn, int T
 #define LH_GEMM_PASS A, Bm, Cm, M, N, K, lda, ldb, strideA, strideB, imgA, imgB, ldc, strideC, scale, nbatch, tiles_m, tiles_n, tn_begin, Bn, T
+#if defined(LH_LEGACY)
 template <int EPI, bool RAGGED, int MODE>
 __global__ void __launch_bounds__(256, 2) k_gemm_nt3(LH_GEMM_ARGS) { gemm_nt3_body<EPI, RAGGED, MODE>(LH_GEMM_PASS); }
+#endif
 template <int EPI, bool RAGGED>
 __global__ void __launch_bounds__(256, 3) k_gemm_nt3_occ3(LH_GEMM_ARGS) { gemm_nt3_body<EPI, RAGGED, 3>(LH_GEMM_PASS); }
 // the 128 + 16 column tile: ~190 VGPRs (two more accumulator tiles, the 17th sub-tile's fragments and staging) = two
@@ -1763,7 +1765,7 @@ static int g_gemm_v = 3;                // lh_set_tuning key 17: k_gemm_nt3 pipe
 int emb_set(int key, int value) {
     if ((key != 16 && key != 17) || value < 0 || value > (key == 17 ? 3 : 1)) return LH_ERR_ARG;
 #if !defined(LH_LEGACY)
-    if (key == 17 && value == 0) return LH_ERR_UNSUPPORTED;
+    if (key == 17 && value != 3) return LH_ERR_UNSUPPORTED;     // the other GEMM pipelines exist in lab builds only
 #endif
     if (key == 16) g_rec_prio = value;
     else g_gemm_v = value;
@@ -1845,9 +1847,12 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
     // scores: every column tile on the straight-line kernel (the last one wastes <= 1 sub-tile of 80)
 #define LH_QK_LAUNCH(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(nb8 * tm * tm), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)k, sc, T, T, \
     EQP, EQP, EQP, (long)T * EQP, (long)T * EQP, img_qk, img_qk, Tp, (long)T * Tp, 1.0f / sqrtf((float)EDQK), nb, tm, tm, 0, B, T)
-    if (g_gemm_v == 3) LH_QK_LAUNCH((k_gemm_nt3_occ3<0, false>));
-    else if (g_gemm_v == 2) LH_QK_LAUNCH((k_gemm_nt3<0, false, 2>));
-    else LH_QK_LAUNCH((k_gemm_nt3<0, false, 1>));
+#if defined(LH_LEGACY)       // lab builds keep the measured-slower pipelines selectable (profiles/r05d_gemm_pipelines.txt)
+    if (g_gemm_v == 2) LH_QK_LAUNCH((k_gemm_nt3<0, false, 2>));
+    else if (g_gemm_v == 1) LH_QK_LAUNCH((k_gemm_nt3<0, false, 1>));
+    else
+#endif
+    LH_QK_LAUNCH((k_gemm_nt3_occ3<0, false>));
 #undef LH_QK_LAUNCH
     const long rows = (long)nb * T;
     {
@@ -1878,14 +1883,18 @@ extern "C" int lh_emb_attn_block(const float* y2, const void* wqkv_pk, const flo
         const int tn_full = EDV / 128;            // 8 full column tiles on the straight-line kernel, the ragged ninth on its own
 #define LH_PV_LAUNCH(KERNEL, NT, TB) hipLaunchKernelGGL(KERNEL, dim3(nb8 * tm * (NT)), dim3(256), 0, st, (const _Float16*)p, (const _Float16*)vt, \
     merged, T, EDV, Tp, Tp, Tp, (long)T * Tp, (long)EDV * Tp, img_p, img_vt, 0, 0L, 1.0f, nb, tm, (NT), (TB), B, T)
-        if (g_gemm_v == 3 && EDV % 128 == 16 && tn_full >= 1) {
-            // default: three workgroups per CU; the 16 columns behind the last full tile ride on it (EXTRA) — no ragged launch
-            if (tn_full > 1) LH_PV_LAUNCH((k_gemm_nt3_occ3<1, false>), tn_full - 1, 0);
-            LH_PV_LAUNCH((k_gemm_nt3_wide<1>), 1, tn_full - 1);
-        } else {
+        static_assert(EDV % 128 == 16 && EDV / 128 >= 1, "the wide last column tile takes exactly 16 columns behind the full tiles");
+#if defined(LH_LEGACY)
+        if (g_gemm_v == 1 || g_gemm_v == 2) {
             if (g_gemm_v == 2) LH_PV_LAUNCH((k_gemm_nt3<1, false, 2>), tn_full, 0);
             else LH_PV_LAUNCH((k_gemm_nt3<1, false, 1>), tn_full, 0);
             if (tn > tn_full) LH_PV_LAUNCH((k_gemm_nt3<1, true, 1>), tn - tn_full, tn_full);
+        } else
+#endif
+        {
+            // three workgroups per CU; the 16 columns behind the last full tile ride on it (k_gemm_nt3_wide) — no ragged launch
+            if (tn_full > 1) LH_PV_LAUNCH((k_gemm_nt3_occ3<1, false>), tn_full - 1, 0);
+            LH_PV_LAUNCH((k_gemm_nt3_wide<1>), 1, tn_full - 1);
         }
 #undef LH_PV_LAUNCH
     }

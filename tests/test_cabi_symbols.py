@@ -46,6 +46,9 @@ def test_hip_library_builds_loads_and_exports():
     import ctypes
     assert not hasattr(ctypes.CDLL(lib.path), "lh_emb_axis")
     assert lib.raw("lh_set_tuning")(2, 2) == 2 and lib.raw("lh_set_tuning")(2, 0) == 0
+    for v in (0, 1, 2):                                   # the attention GEMM's measured-slower pipelines: lab builds only
+        assert lib.raw("lh_set_tuning")(17, v) == 2
+    assert lib.raw("lh_set_tuning")(17, 3) == 0
     assert lib.raw("lh_abi_version")() == _cabi.ABI_VERSION
     assert lib.raw("lh_check_config")(192, 128, 2, 64, 3, 64, 4, 50, 2, 256) == 0
 
