@@ -1321,8 +1321,15 @@ __device__ __forceinline__ void gemm_nt3_body(const _Float16* __restrict__ A, co
     // tile 7 instead of a ninth, ragged tile that re-read all of P for 1.5 % of the columns — 0.39 ms per call).  The 17th
     // sub-tile is split by ROWS so that every wave gets the same extra work: wave (wm, wn) computes rows wm*64 + (2 wn + ii)*16,
     // ii = 0, 1, of it (6 MFMAs per k-step on A fragments it has loaded anyway).
-    constexpr int RPB = EXTRA ? GM_RP + 16 : GM_RP, IMGB = 4 * RPB * 8;
-    constexpr int STAGE_HALVES = 2 * GM_IMG + 2 * IMGB;
+    // LDS image of an operand stage: four 16-byte k-block planes of RP rows, row r of plane kb in slot kb * RP + (r ^ 2 kb).
+    // RP is a multiple of 16 slots (no padding) and the XOR does the de-conflicting for BOTH access shapes: ds_read_b128 is
+    // served in the lane groups {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md, LDS) — a fragment read's group is rows
+    // {0-3, 12-15} of plane g4 and rows {4-11} of plane g4 + 1: sixteen distinct slots mod 16 exactly when RP = 0 mod 16
+    // (until r05i RP was padded to 130 for the staging stores: every fragment read 2-way conflicted, SQ_LDS_BANK_CONFLICT =
+    // 0.333 of the LDS cycles, to the digit); ds_write_b128 is served in 8-lane groups = rows {s, s + 1} x planes 0..3
+    // -> slots (s ^ {0, 2, 4, 6}) and ((s + 1) ^ {0, 2, 4, 6}) mod 8: all different.
+    constexpr int RPA = 128, RPB = EXTRA ? 144 : 128, IMGA = 4 * RPA * 8, IMGB = 4 * RPB * 8;
+    constexpr int STAGE_HALVES = 2 * IMGA + 2 * IMGB;
     __shared__ __attribute__((aligned(16))) _Float16 sm[NSTAGE][STAGE_HALVES];   // [stage][A hi | A lo | B hi | B lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
@@ -1339,11 +1346,12 @@ __device__ __forceinline__ void gemm_nt3_body(const _Float16* __restrict__ A, co
     const int sr = tid >> 2, sb = tid & 3;
     const long a_off0 = (long)min(m0 + sr, M - 1) * lda + sb * 8, a_off1 = (long)min(m0 + sr + 64, M - 1) * lda + sb * 8;
     const long b_off0 = (long)min(n0 + sr, N - 1) * ldb + sb * 8, b_off1 = (long)min(n0 + sr + 64, N - 1) * ldb + sb * 8;
-    const int s_idx0 = (sb * GM_RP + sr) * 8, s_idx1 = (sb * GM_RP + sr + 64) * 8;
-    const int sb_idx0 = (sb * RPB + sr) * 8, sb_idx1 = (sb * RPB + sr + 64) * 8;
+    const int srx = sr ^ (2 * sb), lx = l15 ^ (2 * g4);          // swizzled row within its 16-row group (staging / fragment side)
+    const int s_idx0 = (sb * RPA + srx) * 8, s_idx1 = (sb * RPA + srx + 64) * 8;
+    const int sb_idx0 = (sb * RPB + srx) * 8, sb_idx1 = (sb * RPB + srx + 64) * 8;
     // EXTRA: B rows 128 .. 143 of the tile = 64 more 16-byte items per image: threads 0 .. 63 (wave 0), one hi + one lo each
     const long bx_off = (long)min(n0 + 128 + sr, N - 1) * ldb + sb * 8;
-    const int sbx_idx = (sb * RPB + 128 + sr) * 8;
+    const int sbx_idx = (sb * RPB + 128 + srx) * 8;
     constexpr int NSET = MODE == 2 ? 2 : 1;
     f16x8 st[NSET][8], stx[NSET][2];
     auto fetch = [&](auto set_, int k0) {
@@ -1372,12 +1380,12 @@ __device__ __forceinline__ void gemm_nt3_body(const _Float16* __restrict__ A, co
     auto kstep = [&](int ks, auto set_) __attribute__((always_inline)) {
         constexpr int q = decltype(set_)::value;
         _Float16* buf = &sm[NSTAGE == 2 ? (ks & 1) : 0][0];
-        _Float16* bufb = buf + 2 * GM_IMG;                        // B hi image, B lo image IMGB halves behind it
+        _Float16* bufb = buf + 2 * IMGA;                          // B hi image, B lo image IMGB halves behind it
         if (NSTAGE == 1) __syncthreads();                         // every wave has read the previous k-step's fragments
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx0]) = st[q][2 * i];
-            *reinterpret_cast<f16x8*>(&buf[i * GM_IMG + s_idx1]) = st[q][2 * i + 1];
+            *reinterpret_cast<f16x8*>(&buf[i * IMGA + s_idx0]) = st[q][2 * i];
+            *reinterpret_cast<f16x8*>(&buf[i * IMGA + s_idx1]) = st[q][2 * i + 1];
             *reinterpret_cast<f16x8*>(&bufb[i * IMGB + sb_idx0]) = st[q][4 + 2 * i];
             *reinterpret_cast<f16x8*>(&bufb[i * IMGB + sb_idx1]) = st[q][4 + 2 * i + 1];
         }
@@ -1393,21 +1401,21 @@ __device__ __forceinline__ void gemm_nt3_body(const _Float16* __restrict__ A, co
         f16x8 bh[4], bl[4];
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) {
-            const int idx = (g4 * RPB + wn * 64 + jn * 16 + l15) * 8;
+            const int idx = (g4 * RPB + wn * 64 + jn * 16 + lx) * 8;
             bh[jn] = *reinterpret_cast<const f16x8*>(&bufb[idx]);
             bl[jn] = *reinterpret_cast<const f16x8*>(&bufb[IMGB + idx]);
         }
         f16x8 bxh, bxl;
         if (EXTRA) {
-            const int idx = (g4 * RPB + 128 + l15) * 8;
+            const int idx = (g4 * RPB + 128 + lx) * 8;
             bxh = *reinterpret_cast<const f16x8*>(&bufb[idx]);
             bxl = *reinterpret_cast<const f16x8*>(&bufb[IMGB + idx]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = (g4 * GM_RP + wm * 64 + i * 16 + l15) * 8;
+            const int idx = (g4 * RPA + wm * 64 + i * 16 + lx) * 8;
             const f16x8 ah = *reinterpret_cast<const f16x8*>(&buf[idx]);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(&buf[GM_IMG + idx]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&buf[IMGA + idx]);
             // small terms first; the three products of one tile are four MFMAs apart (no back-to-back dependent MFMAs)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
