@@ -181,22 +181,27 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
         // gridDim.y-th round of column groups — a chunk of ONE frame would otherwise keep 4 of the 256 CUs busy
         const int part = blockIdx.y, nsplit = gridDim.y;
         // key row of (step ks, slot j) for this lane: 32 ks + 8 g4 + j; rows >= NKEYS are never needed (P = 0 there)
-        const int lrow = g4 * 8 * LDVH;
         auto qcol = [&](int cg) { return min(min(cg, AT_CG - 1) * 16 + l15, DV / 4 - 1) * 8; };   // quad offset in halves
         // Register ring over the flattened (column group, key step) sequence of this wave: step s uses slot s % RING
         // and, before its MFMAs, refills the slot of step s-1 with the rows of step s+RING-1.
         VQuad ring[RING][8];
+        // Every load is UNCONDITIONAL (round 5): a lane whose row is >= NKEYS (last key step only: P is exactly 0 there, and
+        // 0 * finite = 0) reads the row the lanes one quarter below load in the SAME instruction (same cache lines, no extra
+        // traffic) instead of skipping the load.  Behind the per-lane `row < NKEYS` branches of rounds 1-4 hipcc lost count
+        // of the loads in flight and drained them all (s_waitcnt vmcnt(0) right behind the refill, once per column group:
+        // the whole L2 latency exposed); in straight-line code the waits are exact and the refill stays in flight.
         auto fill = [&](int slot, int ks, int qc) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                VQuad v;
-                v.h = f16x4{0, 0, 0, 0};
-                v.l = f16x4{0, 0, 0, 0};
-                if (32 * ks + 8 * g4 + j < NKEYS) {
-                    const _Float16* p = vb + lrow + (32 * ks + j) * LDVH + qc;
-                    v.h = *reinterpret_cast<const f16x4*>(p);
-                    v.l = *reinterpret_cast<const f16x4*>(p + 4);
+                int r = 32 * ks + 8 * g4 + j;
+                if (32 * ks + 31 >= NKEYS) {                   // (compile-time per unrolled step: the last key step only)
+                    r = r >= NKEYS ? r - 8 : r;
+                    r = r >= NKEYS ? NKEYS - 1 : r;
                 }
+                const _Float16* p = vb + r * LDVH + qc;
+                VQuad v;
+                v.h = *reinterpret_cast<const f16x4*>(p);
+                v.l = *reinterpret_cast<const f16x4*>(p + 4);
                 ring[slot][j] = v;
             }
         };
@@ -218,7 +223,10 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
             }
             {
                 const int sn = s + RING - 1, cgn = wave + 4 * (part + nsplit * (sn / AT_PKS));
-                if (cgn < AT_CG) fill(sn % RING, sn % AT_PKS, qcol(cgn));
+                fill(sn % RING, sn % AT_PKS, qcol(cgn));      // (no `cgn < AT_CG` branch: qcol clamps, the wave's last refill is a re-read)
+                // the refill goes out HERE: without the fence hipcc sinks the loads below this step's MFMAs, next to their
+                // first use (it saves the ring's registers that way) and every step waits out a full V-row load
+                __builtin_amdgcn_sched_barrier(0);
             }
             // regroup: column tile c takes element c of the 8 key rows -> one f16x8 B operand (hi and lo)
             f16x8 bh8[4], bl8[4];

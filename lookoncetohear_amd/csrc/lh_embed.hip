@@ -833,12 +833,29 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
 // fp16 hi | lo hidden-state images.  One tile = 64 consecutive output positions of ONE sequence: its 67 rows of h are
 // staged once (16-byte copies, no conversion; zero rows outside 0..P-1) and the transposed conv's taps are row offsets
 // in the A-fragment address (k-step ks covers tap ks / 4, hidden columns 32 (ks & 3) ..), like k_emb_gx's unfold.
+#if defined(CT_ODD_PITCH)
+__device__ __forceinline__ constexpr int ct_swz(int) { return 0; }
+#else
+__device__ __forceinline__ constexpr int ct_swz(int kb) { return (kb >> 1) & 3; }     // (see CtShape::RP)
+#endif
 template <bool INTER>
 struct CtShape {                                   // 16-row MFMA tiles per workgroup tile: the intra axis has 65 positions per
     static constexpr int MT = INTER ? 4 : 5;       // sequence — one tile of 80 (5 row tiles) instead of 64 + 1 (8 row tiles)
     static constexpr int RT = 16 * MT;             // output positions per tile
     static constexpr int ROWS = RT + EKS - 1;      // staged h rows
+#if defined(CT_ODD_PITCH)
     static constexpr int RP = ROWS | 1;            // odd row pitch in 16-byte slots
+#else
+    // row pitch in 16-byte slots: a multiple of 16, row r of k-block plane kb in slot kb * RP + (r ^ ct_swz(kb)).  A fragment
+    // read's ds_read_b128 lane group is rows {0-3, 12-15} + r0 of plane kb and rows {4-11} + r0 of plane kb + 1 (kb even):
+    // complementary residues mod 16 whatever the tap offset r0 is, PROVIDED both planes sit at the same residue and share
+    // their XOR — the odd pitch of round 4 (conflict-free staging stores) made every fragment read 2-way conflicted
+    // (SQ_LDS_BANK_CONFLICT 0.46 of the LDS cycles, the LDS 0.5 busy: with four waves re-reading the same A fragments the
+    // MFMA phase needed more LDS cycles than matrix cycles).  The staging stores (eight planes of one row per 8-lane group)
+    // are 2-way now: 16 array cycles against the 13 a ds_write_b128 costs anyway.
+    static constexpr int RP = (ROWS + 15) / 16 * 16;
+#endif
+    static constexpr int NXP = INTER ? MT : 3;     // residual rows prefetched across the MFMA phase (the 80-row tile has registers for 3 of 5)
     static constexpr int NLD = (ROWS * 16 + 255) / 256;
 };
 template <bool INTER>
@@ -849,7 +866,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
     // xs_next != NULL: the rows also leave channel-normalised and split (k_emb_lnsplit's images) for the NEXT axis pass, whose
     // own normalisation launch (a read + a write of the whole activation) then drops out
     using S = CtShape<INTER>;
-    constexpr int KS = 16, CSP = C + 4, MT = S::MT, RT = S::RT, ROWS = S::ROWS, RP = S::RP, NLD = S::NLD;
+    constexpr int KS = 16, CSP = C + 4, MT = S::MT, RT = S::RT, ROWS = S::ROWS, RP = S::RP, NLD = S::NLD, NXP = S::NXP;
     __shared__ __attribute__((aligned(16))) _Float16 ahi[16 * RP * 8];
     __shared__ __attribute__((aligned(16))) _Float16 alo[16 * RP * 8];
     __shared__ __attribute__((aligned(16))) float cs[RT * CSP];
@@ -892,13 +909,21 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + 256 * i;
             if (e < ROWS * 16) {
-                const int idx = ((e & 15) * RP + (e >> 4)) * 8;
+                const int idx = ((e & 15) * RP + ((e >> 4) ^ ct_swz(e & 15))) * 8;
                 *reinterpret_cast<f16x8*>(&ahi[idx]) = sh[i];
                 *reinterpret_cast<f16x8*>(&alo[idx]) = sl[i];
             }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        // the residual rows of this tile go out HERE and are in flight across the MFMA phase (loaded in the epilogue their
+        // latency was exposed once per tile: -13 % / -6 % of the intra / inter launch, profiles/r05k_convt2_ab.txt)
+        float4 xpre[NXP];
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int rr = (tid + 256 * i) >> 4;
+            xpre[i] = *reinterpret_cast<const float4*>(&x[pos_row<INTER>(s, q0 + (rr < valid ? rr : 0), T) * C + (tid & 15) * 4]);
+        }
 #pragma unroll 1
         for (int m = 0; m < MT; ++m) {
             if (m * 16 >= valid) break;                  // (workgroup-uniform) row tiles past the sequence's last position
@@ -906,7 +931,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 // output row m*16 + l15 = position q0 + that; tap k = ks >> 2 reads h row q - k = staged row (.. + 3 - k)
-                const int idx = (((ks & 3) * 4 + g4) * RP + m * 16 + l15 + (EKS - 1) - (ks >> 2)) * 8;
+                const int idx = (((ks & 3) * 4 + g4) * RP + ((m * 16 + l15 + (EKS - 1) - (ks >> 2)) ^ ct_swz((ks & 3) * 4 + g4))) * 8;
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
                 am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
@@ -923,7 +948,7 @@ __global__ void __launch_bounds__(256, 2) k_emb_convt2(const _Float16* __restric
             const bool ok = rr < valid;                  // (uniform over the 16 lanes of a row)
             const long r = pos_row<INTER>(s, q0 + (ok ? rr : 0), T);
             const float4 cv = *reinterpret_cast<const float4*>(&cs[rr * CSP + c4 * 4]);
-            const float4 xv = *reinterpret_cast<const float4*>(&x[r * C + c4 * 4]);
+            const float4 xv = i < NXP ? xpre[i < NXP ? i : 0] : *reinterpret_cast<const float4*>(&x[r * C + c4 * 4]);
             const float4 ov = make_float4(cv.x + xv.x, cv.y + xv.y, cv.z + xv.z, cv.w + xv.w);
             if (ok) *reinterpret_cast<float4*>(&out[r * C + c4 * 4]) = ov;
             if (xs_next) ln_split_store(ov, xs_next, xs_next + rows_x * C, r * C + c4 * 4, ok);
@@ -967,6 +992,17 @@ __device__ __forceinline__ void e_ln_head(const float* ys, int yp, int col0, con
                                           const float* __restrict__ gb, float* __restrict__ dst, int lane) {
     constexpr int N = EF * D, IT = (N + 63) / 64;
     auto at = [&](int k) -> float { const int i = lane + 64 * k; return i < N ? ys[(i / D) * yp + col0 + (i % D)] : 0.f; };
+    // the affine of this lane's slots goes into registers FIRST, in flight under the two reductions: read inside the store
+    // loop, hipcc ordered every (gw[i], gb[i]) pair behind the previous dst[i] store (it does not carry the kernel's
+    // __restrict__ through the inlined lambda): 17 rounds of load -> s_waitcnt vmcnt(0) -> store per frame and head, the
+    // exposed L2 latency of which was most of k_emb_qkv's frame time (round 5: 1.49 -> see profiles/r05k)
+    float aw[IT], ab[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = min(lane + 64 * k, N - 1);
+        aw[k] = gw[i];
+        ab[k] = gb[i];
+    }
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < IT; ++k) s += at(k);
@@ -978,7 +1014,7 @@ __device__ __forceinline__ void e_ln_head(const float* ys, int yp, int col0, con
 #pragma unroll
     for (int k = 0; k < IT; ++k) {
         const int i = lane + 64 * k;
-        if (i < N) dst[i] = (at(k) - mean) * rstd * gw[i] + gb[i];
+        if (i < N) dst[i] = (at(k) - mean) * rstd * aw[k] + ab[k];
     }
 }
 
@@ -991,6 +1027,13 @@ __device__ __forceinline__ void e_ln_head_split(const float* ys, int yp, int col
     constexpr int N = EF * D, IT = (EQP + 63) / 64;
     static_assert(N <= EQP, "row pitch");
     auto at = [&](int k) -> float { const int i = lane + 64 * k; return i < N ? ys[(i / D) * yp + col0 + (i % D)] : 0.f; };
+    float aw[IT], ab[IT];                          // affine first, in flight under the reductions (see e_ln_head)
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = min(lane + 64 * k, N - 1);
+        aw[k] = gw[i];
+        ab[k] = gb[i];
+    }
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < IT; ++k) s += at(k);
@@ -1003,7 +1046,7 @@ __device__ __forceinline__ void e_ln_head_split(const float* ys, int yp, int col
     for (int k = 0; k < IT; ++k) {
         const int i = lane + 64 * k;
         if (i < EQP) {
-            const float o = i < N ? (at(k) - mean) * rstd * gw[i] + gb[i] : 0.f;
+            const float o = i < N ? (at(k) - mean) * rstd * aw[k] + ab[k] : 0.f;
             _Float16 h, l;
             split_hl(o, h, l);
             dh[i] = h;
