@@ -1,0 +1,43 @@
+"""CPU: the compiled gfx950 code of the frame kernels must not contain the load patterns round 5 removed (scripts/isa_waits.py):
+a store loop the compiler serialised against its own loads (k_emb_qkv had 17 rounds of load -> s_waitcnt vmcnt(0) -> store per
+frame and head), or a P.V refill of k_local_attn that is waited for right behind its issue.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+pytestmark = pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not found")
+
+
+@pytest.fixture(scope="module")
+def isa():
+    import isa_waits
+    from lookoncetohear_amd import build
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for src in ("lh_embed.hip", "lh_attn.hip"):
+            out[src] = dict(isa_waits.kernels(isa_waits.disassemble(os.path.join(build.CSRC, src), tmp)))
+    return isa_waits, out
+
+
+def test_no_serialised_load_store_rounds_in_the_embedder_kernels(isa):
+    isa_waits, out = isa
+    for name, ins in out["lh_embed.hip"].items():
+        _, serial = isa_waits.scan(ins, 25)
+        assert serial < 3, f"{name}: {serial} rounds of load -> vmcnt(0) -> store (a store loop serialised against its loads)"
+
+
+def test_attention_value_refill_stays_in_flight(isa):
+    """k_local_attn<3, 2, 40> (the batch-32 shape): behind the prologue (the first 10 % of the instructions) no wait may name a
+    load issued fewer than 8 instructions earlier, except in the last 15 % (the last column group drains by construction)."""
+    isa_waits, out = isa
+    name = next(n for n in out["lh_attn.hip"] if "k_local_attnILi3ELi2ELi40" in n)
+    ins = out["lh_attn.hip"][name]
+    short, _ = isa_waits.scan(ins, 8)
+    mid = [h for h in short if 0.10 * len(ins) < h[0] < 0.85 * len(ins)]
+    assert not mid, mid
