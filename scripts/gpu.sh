@@ -83,5 +83,20 @@ profile_embed)      # the same evidence set for BASELINE configs[4] (VERDICT r4 
     [ -f $R/gpurun_out/pmc_traffic.json ] || cp $R/profiles/pmc_traffic.json $R/gpurun_out/pmc_traffic.json
     python $R/scripts/make_pmc_traffic_embed.py $R/gpurun_out/embed_kernel_stats.csv $R/gpurun_out/embed_pmc_FETCH_SIZE.csv $R/gpurun_out/embed_pmc_WRITE_SIZE.csv 64 5 $R/gpurun_out/pmc_traffic.json $R/gpurun_out/embed_pmc_sq.csv $R/gpurun_out/embed_pmc_sq2.csv
     cd $R; head -24 gpurun_out/embed_kernel_stats.csv ;;
+round_end)          # one call for a small change late in a round: same-box A/B against LIBS' first entry, the default bench line,
+                    # kernel stats + the dispatch timeline of one step, then the GPU suite and smoke (most valuable first)
+    for rep in 1 2; do for lib in ${LIBS:-_lookonce_hip_old.so _lookonce_hip.so}; do
+        LOOKONCE_HIP_LIB=$R/lookoncetohear_amd/$lib timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-power --no-gpu-library-baseline > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
+        bench_line gpurun_out/bench_ab.json "$lib B=32"
+    done; done | tee gpurun_out/ab_round_end.txt
+    timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+    cut -c1-600 gpurun_out/bench.json
+    ( cd /tmp && export TMPDIR=/tmp
+      timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o r1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-power --no-gpu-library-baseline > $R/gpurun_out/prof_stats.log 2>&1; echo "rocprof rc=$?"
+      python $R/scripts/rocpd_summary.py /tmp/prof_stats/r1_results.db $R/gpurun_out/kernel_stats.csv
+      python $R/scripts/rocpd_summary.py /tmp/prof_stats/r1_results.db $R/gpurun_out/step_timeline.txt --timeline )
+    tail -3 gpurun_out/step_timeline.txt
+    timeout ${SUITE_TIMEOUT:-560} python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/pytest_gpu.txt
+    timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -i smoke | tee -a gpurun_out/pytest_gpu.txt ;;
 *)  echo "unknown task $task"; exit 2 ;;
 esac

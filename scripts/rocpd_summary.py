@@ -2,6 +2,9 @@
 
     python scripts/rocpd_summary.py <results.db> <out.csv>          # kernel stats (top_kernels view)
     python scripts/rocpd_summary.py <results.db> <out.csv> --pmc    # per-kernel average of each collected counter
+    python scripts/rocpd_summary.py <results.db> <out.txt> --timeline [marker]   # every dispatch of the LAST step (between the
+                                              # last two dispatches whose name contains `marker`, default k_stft_conv_in):
+                                              # name, duration, gap to the previous dispatch's end — what a step consists of
 """
 import csv
 import sqlite3
@@ -12,6 +15,42 @@ def short(name):
     if name.startswith("_ZN2lh12k_ln_lstm_h3ILi"):
         return "lh::k_ln_lstm_h3<%s>" % name[len("_ZN2lh12k_ln_lstm_h3ILi")]
     return name.split("(")[0].replace("void ", "")[:100]
+
+
+def timeline(db, out, marker):
+    c = sqlite3.connect(db)
+    objs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+    for t in sorted(objs, key=lambda n: (not n.startswith("kernels"), n)):
+        try:
+            tc = [r[1] for r in c.execute(f"pragma table_info('{t}')")]
+        except Exception:
+            continue
+        ncol = next((x for x in ("name", "kernel_name", "kernel") if x in tc), None)
+        if not (ncol and "start" in tc and "end" in tc):
+            continue
+        rows = c.execute(f"select {ncol}, start, end from '{t}' order by start").fetchall()
+        marks = [i for i, r in enumerate(rows) if isinstance(r[0], str) and marker in r[0]]
+        if len(marks) < 2:
+            continue
+        a, b = marks[-2], marks[-1]
+        with open(out, "w") as f:
+            f.write(f"# dispatches {a}..{b - 1} of {t}: one step, from `{marker}` to the next one (us)\n")
+            f.write(f"# {'kernel':<60} {'dur_us':>9} {'gap_us':>8}\n")
+            tot = gaps = small = 0.0
+            for i in range(a, b):
+                n, st, en = rows[i]
+                gap = (st - rows[i - 1][2]) / 1e3 if i > a else 0.0
+                d = (en - st) / 1e3
+                tot += d
+                gaps += max(gap, 0.0)
+                if d < 100.0:
+                    small += d
+                f.write(f"{short(n)[:60]:<62} {d:9.1f} {gap:8.1f}\n")
+            f.write(f"# span {(rows[b][1] - rows[a][1]) / 1e3:.1f} us = kernels {tot:.1f} + gaps {gaps:.1f}; "
+                    f"dispatches shorter than 100 us: {small:.1f} us\n")
+        print("wrote", out, b - a, "dispatches")
+        return
+    print("no table with a name / start / end and two markers; objects:", " ".join(objs))
 
 
 def main(db, out, pmc=False):
@@ -84,4 +123,8 @@ def main(db, out, pmc=False):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], "--pmc" in sys.argv)
+    if "--timeline" in sys.argv:
+        i = sys.argv.index("--timeline")
+        timeline(sys.argv[1], sys.argv[2], sys.argv[i + 1] if len(sys.argv) > i + 1 else "k_stft_conv_in")
+    else:
+        main(sys.argv[1], sys.argv[2], "--pmc" in sys.argv)
