@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) k_embed_proj(const float* __restrict__ em
     }
     __syncthreads();
     // a wave's 8 rows of W and their biases are fetched up front (8 independent 16-byte loads per lane in flight; one row
-    // per loop trip exposed the load latency 8 times: 17.8 us per call for 6.4 MB)
+    // per loop trip exposed the load latency 8 times; 17.8 -> 16.8 us per call, profiles/r05o_*)
     constexpr int RW = EP_ROWS / 4;
     float4 w4[RW];
     float bz[RW];
@@ -247,14 +247,12 @@ __global__ void __launch_bounds__(256) k_embed_ln(const float* __restrict__ raw,
     float v = 0.0f;
     for (int i = tid; i < N; i += 256) { float d = vals[i] - mean; v += d * d; }
     const float rstd = rsqrtf(block_sum_256(v, red) * (1.0f / N) + LN_EPS);
-    // affine in the reference's flat order i = c * NF + f (channel-major, reshape [B,C,F]): coalesced reads of the LayerNorm
-    // weights; the (c,f) -> (f,c) transpose happens on the way out of LDS (stride NF = 97 words: conflict-free).  Rounds 1-4
-    // gathered lnw / lnb with that stride from global memory: 17.4 us per call.
-    for (int i = tid; i < N; i += 256) vals[i] = (vals[i] - mean) * rstd * lnw[i] + lnb[i];
-    __syncthreads();
+    // (the coalesced form — affine in i order back into LDS, transpose on the way out — measured 19.4-20.0 us against 17.4 for
+    // this strided gather of lnw / lnb: one more barrier and LDS pass than the gather costs; profiles/r05o_*)
     for (int oidx = tid; oidx < N; oidx += 256) {
         const int f = oidx / C, c = oidx % C;
-        gain[(long)b * N + oidx] = vals[c * NF + f];
+        const int i = c * NF + f;                     // reference flat order is channel-major (reshape [B,C,F])
+        gain[(long)b * N + oidx] = (vals[i] - mean) * rstd * lnw[i] + lnb[i];
     }
 }
 

@@ -98,5 +98,18 @@ round_end)          # one call for a small change late in a round: same-box A/B 
     tail -3 gpurun_out/step_timeline.txt
     timeout ${SUITE_TIMEOUT:-560} python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/pytest_gpu.txt
     timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -i smoke | tee -a gpurun_out/pytest_gpu.txt ;;
+timelines)          # dispatch timelines of one step (scripts/rocpd_summary.py --timeline): the B=32 forward with the default kernels and
+                    # with TUNES' switches, one embedder forward on one stream; then the default bench line
+    cd /tmp && export TMPDIR=/tmp
+    for t in ${TUNES:-_ 5=2}; do
+        ta=""; [ "$t" != "_" ] && ta="--tune $t"
+        timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/tl_$t -o r1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-power --no-gpu-library-baseline $ta > $R/gpurun_out/tl_$t.log 2>&1; echo "rocprof $t rc=$?"
+        python $R/scripts/rocpd_summary.py /tmp/tl_$t/r1_results.db $R/gpurun_out/step_timeline_$t.txt --timeline
+    done
+    LOOKONCE_PACK_ON_HOST=1 LOOKONCE_EMB_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/tl_embed -o r1 -- python $R/bench.py --mode embed --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/tl_embed.log 2>&1; echo "rocprof embed rc=$?"
+    python $R/scripts/rocpd_summary.py /tmp/tl_embed/r1_results.db $R/gpurun_out/step_timeline_embed.txt --timeline k_emb_std
+    cd $R
+    timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+    cut -c1-400 gpurun_out/bench.json; tail -3 gpurun_out/step_timeline_*.txt ;;
 *)  echo "unknown task $task"; exit 2 ;;
 esac
