@@ -861,9 +861,14 @@ def main():
         breakdown = durations(net._prof)
         dom = max(breakdown, key=lambda k: breakdown[k]["total_ms"])
         log(f"warm-up done; dominant call {dom}")
-        net._prof, net._prof_only = [], {dom}
+        # Sampled: every 4th call of the dominant entry point is bracketed (3 calls per step, so the samples rotate through
+        # the three blocks).  A HIP event record is not free on the stream: the dispatch timeline of a step showed a 5.6-6.3 us
+        # idle gap at each of the six records of a fully bracketed step (profiles/r05o_b32_step_timeline.txt: 35 us = 0.5 % of
+        # the step was the measurement itself); sampled, the bracket costs ~9 us per step.
+        net._prof, net._prof_only, net._prof_stride, net._prof_count = [], {dom}, int(os.environ.get("LOOKONCE_BENCH_EVENT_STRIDE", "4")), {}
         elapsed, local_elapsed, (y, sums) = timed_region(step, args.steps, dist, dev, torch.cuda.synchronize)
-        prof, net._prof, net._prof_only = net._prof, None, None
+        prof, net._prof, net._prof_only, net._prof_stride = net._prof, None, None, 1
+        roof_samples = len(prof)
     log(f"timed region: {local_elapsed * 1e3 / args.steps:.3f} ms/step (max over ranks {elapsed * 1e3 / args.steps:.3f})")
     # the forwards ran asynchronously (deferred range check, net.py): one look at this Net's flag word for the whole region
     range_flag_raised = bool(net.range_status(dev)) if net.range_check else None
@@ -926,6 +931,7 @@ def main():
         roof["kernel_function"] = KERNEL_NAME.get(dom, dom)
         roof["launches_per_call"] = lpc            # achieved = work of one call / duration of one call (= per launch too)
         roof["avg_call_ms"] = kern[dom]["avg_ms"]
+        roof["event_samples"] = roof_samples       # calls of the dominant entry point bracketed with HIP events in the timed region
         roof["avg_launch_ms"] = kern[dom]["avg_ms"] / lpc
         # the same call in the fully instrumented warm-up step (event pairs around every call, as rocprofv3's tracer
         # also separates the dispatches): the figure to hold against profiles/*kernel_stats*.csv

@@ -184,6 +184,8 @@ class Net(_cabi.HipHost, nn.Module):
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: list of (kernel tag, start event, end event) per launch
         self._prof_only: Optional[set] = None
+        self._prof_stride: int = 1              # bench.py: bracket every n-th call of the selected names only (see bench.py)
+        self._prof_count: dict = {}
         # asteroid-filterbanks' STFTFB may register a second buffer (`torch_window`) next to `_filters` (un-vendored,
         # version unpinned: could not be checked here).  The kernels only need `_filters`, so such keys of a reference
         # checkpoint are dropped before the strict key check instead of failing it.
@@ -381,12 +383,18 @@ class Net(_cabi.HipHost, nn.Module):
             xa, xb, xc, hbuf = ws["xa"], ws["xb"], ws["xc"], ws["hbuf"]
             prof = self._prof
             only = self._prof_only                   # bench.py: restrict the event pairs to these C-ABI calls
+            stride, count = self._prof_stride, self._prof_count
 
             class _Timed:                       # HIP events on the launch stream around each C-ABI call
                 @staticmethod
                 def call(name, *args):
                     if prof is None or (only is not None and name not in only):
                         return lib_.call(name, *args)
+                    if stride > 1:                  # sampled bracket: an event record costs ~6 us of stream time
+                        n = count.get(name, 0)
+                        count[name] = n + 1
+                        if n % stride:
+                            return lib_.call(name, *args)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     lib_.call(name, *args)

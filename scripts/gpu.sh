@@ -111,5 +111,17 @@ timelines)          # dispatch timelines of one step (scripts/rocpd_summary.py -
     cd $R
     timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
     cut -c1-400 gpurun_out/bench.json; tail -3 gpurun_out/step_timeline_*.txt ;;
+final)              # A/B of bench.py's event bracket (every call / every 4th call of the dominant entry point), the default line, the
+                    # embedder line, the GPU suite, smoke
+    for rep in 1 2; do for es in 1 4; do
+        LOOKONCE_BENCH_EVENT_STRIDE=$es timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-power --no-gpu-library-baseline > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
+        bench_line gpurun_out/bench_ab.json "event stride $es B=32"
+    done; done | tee gpurun_out/ab_event_stride.txt
+    timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+    cut -c1-400 gpurun_out/bench.json
+    timeout 300 python bench.py --mode embed > gpurun_out/bench_embed.json 2>> gpurun_out/bench.err; echo "embed rc=$?"
+    cut -c1-300 gpurun_out/bench_embed.json
+    timeout ${SUITE_TIMEOUT:-420} python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/pytest_gpu.txt
+    timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -i smoke | tee -a gpurun_out/pytest_gpu.txt ;;
 *)  echo "unknown task $task"; exit 2 ;;
 esac
