@@ -805,6 +805,27 @@ def secondary_measurements(net, dev, mix8, emb8):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher around it: replace this process with
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same
+    arguments>` — the command the contract names, one rank per GPU; the ranks then take the `WORLD_SIZE` branch of `main`.
+    Under an external torchrun (RANK / WORLD_SIZE set) this is never reached."""
+    import socket
+    if "--dry-run-cpu" not in sys.argv and torch.cuda.device_count() < n:
+        sys.exit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+    with socket.socket() as s_:                                     # a free rendezvous port on the loopback interface
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC for RCCL (task environment)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher: exec {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -827,6 +848,8 @@ def main():
     ap.add_argument("--tune", default="", help="comma list key=value for lh_set_tuning (A/B runs), e.g. 0=2,1=1")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)                               # plain `python bench.py --gpus N`: start the N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -317,16 +317,21 @@ class Net(_cabi.HipHost, nn.Module):
 
     def range_status(self, device=None) -> bool:
         """Waits for the current stream of `device`, then reads and clears this Net's range flag: True when a forward since
-        the last look stored zeros in place of non-finite samples.  Call it after the last forward of a loop (a set flag
-        otherwise raises at the start of the next forward)."""
-        if device is None and not self._range_flags:
-            return False                                      # no forward has run yet
-        dev = torch.device(self._dev_key(device)) if device is not None else torch.device(next(iter(self._range_flags)))
-        flag = self._range_flag(dev)
-        self._sync(dev)
-        bad = int(flag[0]) != 0
-        if bad:
-            flag.zero_()
+        the last look produced non-finite samples.  Call it after the last forward of a loop (a set flag otherwise raises at
+        the start of the next forward).  `device=None`: EVERY device this Net has run on (it used to look at the
+        first one only)."""
+        if device is None:
+            keys = list(self._range_flags)
+        else:
+            keys = [self._dev_key(device)]
+        bad = False
+        for key in keys:
+            dev = torch.device(key)
+            flag = self._range_flag(dev)
+            self._sync(dev)
+            if int(flag[0]) != 0:
+                flag.zero_()
+                bad = True
         return bad
 
     def _sync(self, dev):

@@ -43,7 +43,7 @@ import ctypes, os, sys, json, torch
 sys.path.insert(0, %r)
 import torch.distributed as dist
 from lookoncetohear_amd import _cabi, config, synth
-from lookoncetohear_amd.eval import evaluate
+from lookoncetohear_amd.eval import evaluate, gather_rows
 from lookoncetohear_amd.net import Net
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(rank)
@@ -68,8 +68,9 @@ mine = torch.tensor([sum(r["si_snr_i"] for r in rows), sum(r["output_sisnr"] for
 assert lib.raw("lh_allreduce_f64")(comm, mine.data_ptr(), 4, torch.cuda.current_stream().cuda_stream) == 0
 torch.cuda.synchronize()
 assert lib.raw("lh_comm_destroy")(comm) == 0
+table = gather_rows(rows, 6, world, dev, dist)          # the reference's CSV table across ranks (RCCL all-gather)
 if rank == 0:
-    print("RESULT " + json.dumps({"agg": agg, "cabi": mine.tolist()}))
+    print("RESULT " + json.dumps({"agg": agg, "cabi": mine.tolist(), "table": table}))
 dist.destroy_process_group()
 """ % ROOT
 
@@ -82,8 +83,10 @@ def test_two_ranks_on_rccl(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
               "127.0.0.1", "--master-port", "29547"]
-    out = subprocess.run(launch + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                                   "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    # bench.py launched PLAINLY: it starts its own two ranks under torch.distributed.run
+    plain = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, env=plain, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["metric_sums"][3] == 64.0
@@ -96,8 +99,11 @@ def test_two_ranks_on_rccl(tmp_path):
     net = Net(**config.TSH_PARAMS).eval()
     net.load_state_dict(config.separator_weights(0), strict=True)
     net = net.to("cuda:0")
-    ref, _ = evaluate(net, lambda idx: synth.batch(idx, 16000), n_utts=6, batch_size=2, device="cuda:0")
+    ref, ref_rows = evaluate(net, lambda idx: synth.batch(idx, 16000), n_utts=6, batch_size=2, device="cuda:0")
     assert got["agg"]["n"] == 6 and got["cabi"][3] == 6.0
+    assert [t["idx"] for t in got["table"]] == list(range(6))
+    for t, q in zip(got["table"], ref_rows):
+        assert t["idx"] == q["idx"] and abs(t["si_snr_i"] - q["si_snr_i"]) < 1e-3
     for k in ("si_snr_i", "output_sisnr", "embedding_sim"):
         assert abs(got["agg"][k] - ref[k]) < 1e-4
     assert abs(got["cabi"][0] / 6 - ref["si_snr_i"]) < 1e-3
