@@ -277,6 +277,39 @@ def parity_object(net, dev, dump, sample_clips=4):
             "ok": bool(float((y - y_ref).abs().max()) <= 1e-3 and float((si_h - si_r).abs().max()) <= 0.05 and not bad)}, ref
 
 
+def secondary_parity(sec, kept, ref):
+    """`parity` objects of the secondary legs: the waveforms those legs kept (`kept`: rows 0..3 of
+    the B = 256 batch, row 0 of B = 1, the streamed clip, rows 0..3 of the second in-flight replica — all utterances 0..3) against
+    the reference outputs of the cpu_baseline leg (`ref['y']`, the reference's ATen sequence on the same four clips)."""
+    from lookoncetohear_amd import synth
+    from lookoncetohear_amd.metrics import per_utterance
+    y_ref = torch.from_numpy(ref["y"])
+    b = synth.batch(list(range(y_ref.shape[0])), 80000)
+    e = b["embedding_gt"][:, 0]
+
+    def obj(y, n_samples=None):
+        k = y.shape[0]
+        r, m, t = y_ref[:k], b["mixture"][:k], b["target"][:k]
+        if n_samples is not None:
+            r, m, t = r[..., :n_samples], m[..., :n_samples], t[..., :n_samples]
+        _, si_h, _ = per_utterance(y.double(), m.double(), t.double(), e[:k], e[:k])
+        _, si_r, _ = per_utterance(r.double(), m.double(), t.double(), e[:k], e[:k])
+        ma, ds = float((y - r).abs().max()), float((si_h - si_r).abs().max())
+        return {"max_abs": ma, "d_sisnri_db": ds, "clips": k, "against": "reference ATen sequence fp32 (this run's cpu_baseline leg)",
+                "tolerance": {"max_abs": 1e-3, "d_sisnri_db": 0.05}, "ok": bool(ma <= 1e-3 and ds <= 0.05)}
+
+    for key, leg in (("_y_offline_b1", "offline_b1"), ("_y_offline_b256", "offline_b256"),
+                     ("_y_two_in_flight", "offline_b32_two_in_flight")):
+        if key in kept and isinstance(sec.get(leg), dict):
+            sec[leg]["parity"] = obj(kept[key])
+    if "_y_stream_b1" in kept and isinstance(sec.get("stream_b1"), dict):
+        y = kept["_y_stream_b1"]
+        sec["stream_b1"].setdefault("parity", {}).update(
+            {("vs_reference_" + k if k in ("max_abs", "d_sisnri_db", "ok") else k): v for k, v in obj(y, y.shape[-1]).items()
+             if k != "clips"})
+        sec["stream_b1"]["parity"]["samples"] = int(y.shape[-1])
+
+
 def gpu_library_baseline(sample_clips=4, repeats=3):
     """Context only, not the product and not credit: the reference's own operator sequence
     (`oracle/aten_port.py`, unchanged) on THIS GPU through PyTorch-ROCm's libraries (MIOpen LSTM, rocBLAS / hipBLASLt
@@ -622,6 +655,9 @@ def secondary_measurements(net, dev, mix8, emb8):
                 mix = mix8.repeat((B + 7) // 8, 1, 1)[:B].contiguous()
                 emb = emb8.repeat((B + 7) // 8, 1, 1)[:B].contiguous()
                 ms = _time_forward(lambda: net(mix, emb), 5 if B == 1 else 3, 2)
+                # rows 0..3 (B = 256) / row 0 (B = 1) = utterances 0..3, the clips of the cpu_baseline leg: held against its
+                # reference outputs once that leg has run (`secondary_parity`)
+                out[f"_y_offline_b{B}"] = net(mix, emb)[:4].cpu()
                 out[f"offline_b{B}"] = {"ms_per_step": ms, "frames_per_s": B * FRAMES_PER_CLIP / ms * 1e3,
                                         "rtf": ms * 1e-3 / (B * CLIP_SECONDS),
                                         "workload": f"{B} x 5 s clips, offline forward" +
@@ -676,6 +712,13 @@ def secondary_measurements(net, dev, mix8, emb8):
 
             in_flight(4)
             torch.cuda.synchronize()
+            with torch.cuda.stream(streams[1]):
+                y2 = nets[1](mix, emb)
+            torch.cuda.synchronize()
+            y1 = net(mix, emb)
+            same = bool(torch.equal(y1, y2))
+            out["_y_two_in_flight"] = y2[:4].cpu()
+            del y1, y2
             ms1 = _time_forward(lambda: net(mix, emb), 8, 2)
             t0 = time.perf_counter()
             in_flight(16)
@@ -683,6 +726,7 @@ def secondary_measurements(net, dev, mix8, emb8):
             ms2 = (time.perf_counter() - t0) / 16 * 1e3
             out["offline_b32_two_in_flight"] = {"ms_per_batch": ms2, "ms_per_batch_one_in_flight": ms1, "ratio": ms2 / ms1,
                                                 "frames_per_s": B * FRAMES_PER_CLIP / ms2 * 1e3,
+                                                "replica_bit_identical_to_headline_net": same,
                                                 "workload": "two batch-32 forwards in flight (two Net replicas, two HIP streams, "
                                                             "batches alternating); the headline keeps ONE in flight"}
             log(f"offline B=32, two in flight: {ms2:.3f} ms per batch (one in flight, same loop: {ms1:.3f})")
@@ -698,19 +742,31 @@ def secondary_measurements(net, dev, mix8, emb8):
             st.set_embedding(emb8[:1, 0])
             mixp = torch.nn.functional.pad(mix8[:1], (0, 64))
             chunks = [mixp[:, :, i * 128:i * 128 + 192].contiguous() for i in range(625)]
+            ys = []
             for i in range(20):
-                st.step(chunks[i])
+                ys.append(st.step(chunks[i]).clone())
             torch.cuda.synchronize()
             lat = []
             for i in range(600):
                 t1 = time.perf_counter()
-                st.step(chunks[20 + i])
+                yc = st.step(chunks[20 + i])
                 torch.cuda.synchronize()
                 lat.append((time.perf_counter() - t1) * 1e3)
+                ys.append(yc.clone())                   # outside the latency bracket: `step` hands back a view it overwrites
             lat.sort()
             mean = sum(lat) / len(lat)
+            # parity of the streamed waveform: the 620 chunks (20 warm-up + 600 timed, carried state) against
+            # the OFFLINE HIP forward of the same clip (the reference property streaming == offline), and — after
+            # the cpu leg — against the reference's output of that clip
+            y_stream = torch.cat(ys, dim=-1)
+            y_off = net(mix8[:1], emb8[:1])[..., :y_stream.shape[-1]]
+            out["_y_stream_b1"] = y_stream.cpu()
+            stream_vs_offline = float((y_stream - y_off).abs().max())
+            del ys, y_stream, y_off
             out["stream_b1"] = {"ms_per_chunk": mean, "p50_ms": lat[len(lat) // 2], "p99_ms": lat[int(len(lat) * 0.99)],
                                 "max_ms": lat[-1], "rtf": mean / 8.0, "chunks": len(lat),
+                                "parity": {"max_abs_vs_offline_hip_forward": stream_vs_offline, "chunks": 620, "tolerance": 1e-4,
+                                           "ok": stream_vs_offline <= 1e-4},
                                 "workload": "BASELINE configs[1]: 1 stream, 8 ms chunks (128-sample hop, 64-sample "
                                             "look-ahead), carried state, two alternating HIP graphs"}
             log(f"stream B=1: {mean:.3f} ms/chunk p99 {out['stream_b1']['p99_ms']:.3f}")
@@ -1046,10 +1102,11 @@ def main():
                                     for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["avg_ms"] * breakdown[kv[0]]["launches"])},
             "metric_sums": [float(v) for v in sums.tolist()],
         }
-        emb_rows = None
+        emb_rows, kept = None, {}
         if not args.no_secondary and world == 1 and args.batch == 32 and not args.gemm:
             out["secondary"] = secondary_measurements(net, dev, mix[:8], emb[:8])
             emb_rows = out["secondary"].pop("_embed_b64_rows", None)
+            kept = {k: out["secondary"].pop(k) for k in [k for k in out["secondary"] if k.startswith("_y_")]}
         out["parity"] = None
         if not args.no_cpu_baseline and world == 1:
             import tempfile
@@ -1062,6 +1119,10 @@ def main():
                     try:
                         out["parity"], ref = parity_object(net, dev, dump)
                         log(f"parity: {out['parity']}")
+                        if "secondary" in out:
+                            secondary_parity(out["secondary"], kept, ref)
+                            log("secondary parity: " + json.dumps({k: v.get("parity") for k, v in out["secondary"].items()
+                                                                   if isinstance(v, dict) and "parity" in v}))
                         sec = out.get("secondary", {}).get("embed_b64")
                         if isinstance(sec, dict) and emb_rows is not None and "emb" in ref.files:
                             er = torch.from_numpy(ref["emb"]).double()

@@ -36,10 +36,15 @@ __global__ void __launch_bounds__(ES_NTH) k_emb_std(const float* __restrict__ x,
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid);
     const float* xb = x + (long)blockIdx.x * n;
     double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    // ONE summation order whatever the row's alignment (rows of a batch alternate between aligned and not when
+    // NMIC * n_samples is not a multiple of 4, and the same utterance must give the same bits at every batch position):
+    // element i always goes to thread (i / 4) % ES_NTH, accumulator i % 4; an unaligned row only loads its quads as scalars.
     const bool vec = ((reinterpret_cast<unsigned long long>(xb) & 15ull) == 0ull);
-    const int n4 = vec ? n / 4 : 0;
+    const int n4 = n / 4;
     for (int i = tid; i < n4; i += ES_NTH) {
-        const float4 v4 = *reinterpret_cast<const float4*>(&xb[i * 4]);
+        float4 v4;
+        if (vec) v4 = *reinterpret_cast<const float4*>(&xb[i * 4]);
+        else { v4.x = xb[i * 4]; v4.y = xb[i * 4 + 1]; v4.z = xb[i * 4 + 2]; v4.w = xb[i * 4 + 3]; }
         const double a = v4.x, b = v4.y, c = v4.z, d = v4.w;
         s[0] += a; ss[0] += a * a;
         s[1] += b; ss[1] += b * b;

@@ -157,6 +157,7 @@ class Net(_cabi.HipHost, nn.Module):
         # test-only — the all-fp32 run that separates "split-precision error" from "kernel bug" on a real checkpoint).
         # LOOKONCE_GEMM overrides.
         self.gemm_mode = os.environ.get("LOOKONCE_GEMM", "f16x3")
+        self._check_gemm_mode()                 # a stale LOOKONCE_GEMM=f32 (the spelling removed in round 5) fails HERE
         # range guard of the split-precision kernels (include/lookonce_hip.h): the frame kernels scale every row / tile by
         # a power of two before they split it, so any finite input is in range; non-finite output samples (inf / NaN in
         # the input, a true fp32 overflow) reach the caller AS THEY ARE, like from the reference's plain-fp32 forward
@@ -354,6 +355,7 @@ class Net(_cabi.HipHost, nn.Module):
         if self.training and torch.is_grad_enabled():
             raise RuntimeError("lookoncetohear_amd.Net is an inference-only drop-in (forward kernels, no autograd): call "
                                ".eval() and/or run under torch.no_grad(); training stays on the reference model")
+        self._check_gemm_mode()                 # before the first launch, not mid-forward
         if self.gemm_mode == "f32all":
             return self._separate_ref32(x, embed, state, want_state)
         lib = self._lib(x)
@@ -417,8 +419,6 @@ class Net(_cabi.HipHost, nn.Module):
                 taps["Z0"], taps["G"] = xa.clone(), ws["gain"].clone()
 
             rows = Bn * T * F_
-            if self.gemm_mode not in ("f32rec", "f32all", "f16x3"):
-                raise ValueError(f"gemm_mode must be 'f16x3', 'f32rec' or 'f32all', got {self.gemm_mode!r}")
             mode = 1 if self.gemm_mode == "f16x3" else 0
             wkey, bkey = ("_w16", "_b16") if mode else ("_w", "_b")
             for i in range(self.n_blocks):
@@ -500,6 +500,11 @@ class Net(_cabi.HipHost, nn.Module):
                 if self.range_status(dev):
                     raise RuntimeError(self._RANGE_MSG.format("this forward"))
         return y, (state if want_state else None)
+
+    def _check_gemm_mode(self):
+        if self.gemm_mode not in ("f32rec", "f32all", "f16x3"):
+            raise ValueError(f"gemm_mode / LOOKONCE_GEMM must be 'f16x3', 'f32rec' or 'f32all', got {self.gemm_mode!r}"
+                             + (" ('f32' was the pre-round-5 spelling of 'f32rec')" if self.gemm_mode == "f32" else ""))
 
     def _capturing(self) -> bool:
         return torch.cuda.is_current_stream_capturing()

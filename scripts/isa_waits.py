@@ -19,17 +19,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lookoncetohear_amd import build  # noqa: E402
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def tools():
+    """(hipcc, clang-offload-bundler, llvm-objdump) of the toolchain in use — $HIPCC / PATH / /opt/rocm for hipcc, the llvm
+    directory `build._llvm_bin()` resolves for the other two; a missing one is None (callers skip)."""
+    import shutil
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    llvm = build._llvm_bin()
+    found = [hipcc if os.path.exists(hipcc) or shutil.which(hipcc) else None]
+    for t in ("clang-offload-bundler", "llvm-objdump"):
+        c = os.path.join(llvm, t)
+        found.append(c if os.path.exists(c) else shutil.which(t))
+    return tuple(found)
 
 
 def disassemble(src: str, tmp: str) -> str:
     base = os.path.join(tmp, os.path.basename(src).replace(".hip", ""))
     flags = [f"--offload-arch={build.ARCH}", "--cuda-device-only", "-O3", "-std=c++17", "-ffp-contract=fast", *build.NO_SLP,
              *build.FILE_FLAGS.get(os.path.basename(src), []), "-I", os.path.join(ROOT, "include")]
-    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *flags, "-c", src, "-o", base + ".co"])
-    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={base}.co",
+    hipcc, bundler, objdump = tools()
+    subprocess.check_call([hipcc, *flags, "-c", src, "-o", base + ".co"])
+    subprocess.check_call([bundler, "--unbundle", "--type=o", f"--input={base}.co",
                            f"--targets=hipv4-amdgcn-amd-amdhsa--{build.ARCH}", f"--output={base}.dev.co"])
-    return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", f"--mcpu={build.ARCH}", base + ".dev.co"], text=True)
+    return subprocess.check_output([objdump, "-d", f"--mcpu={build.ARCH}", base + ".dev.co"], text=True)
 
 
 def kernels(asm: str):

@@ -30,7 +30,7 @@ for i in range(20):
     if i == 10:
         e0.record()
     lib.call("lh_deconv_istft", P(xa), P(dec_in), P(dec_out), P(ist_in), P(ist_out), P(pk["deconv_w"]), P(pk["deconv_b"]),
-             P(pk["wfb_dec"]), P(y), None, B, T, st)
+             P(pk["wfb_dec"]), P(y), None, 0, B, T, st)
 e1.record()
 torch.cuda.synchronize()
 print("lh_deconv_istft B=1 T=1: %.2f us per call (back to back)" % (e0.elapsed_time(e1) * 100))

@@ -1,7 +1,7 @@
 """GPU parity tests, part 2 (round-2 VERDICT items): every arithmetic path the library ships is executed on the MI355X
 and held against the reference goldens / the CPU oracle —
 
-  * the exact-fp32 MFMA recurrences (`LOOKONCE_GEMM=f32` -> k_ln_lstm<1|2>) and the unfused split-precision pair
+  * the exact-fp32 MFMA recurrences (`LOOKONCE_GEMM=f32rec` -> k_ln_lstm<1|2>) and the unfused split-precision pair
     (`LOOKONCE_FUSE=0` -> k_ln_lstm_h3<1|2> + k_linear_res), small shapes and the B*T >= 8192 tilings;
   * a ragged fused grid (B = 14: B*T = 8750 and B*97 = 1358 sequences are no multiples of 16) and B = 256 on one GPU;
   * fp16-range stress of the split-precision path: the residual stream scaled up until |v| leaves the fp16 range;

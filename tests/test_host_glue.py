@@ -53,3 +53,19 @@ def test_timeline_of_one_step_from_a_rocpd_database(tmp_path):
     rows = [l for l in lines if not l.startswith("#")]
     assert len(rows) == 3 and rows[0].startswith("lh::k_stft_conv_in") and rows[2].split()[-1] == "6.0"
     assert "kernels 548.0 + gaps 7.5" in lines[-1] and "shorter than 100 us: 8.0 us" in lines[-1]
+
+
+def test_stale_gemm_mode_spelling_fails_at_construction_not_mid_forward(monkeypatch):
+    """`LOOKONCE_GEMM=f32` (the spelling removed in round 5) used to raise only after the front-end kernels of a
+    forward had been launched; it now fails when the Net is built, and an attribute set later is checked before the first launch."""
+    from lookoncetohear_amd import config
+    from lookoncetohear_amd.net import Net
+    monkeypatch.setenv("LOOKONCE_GEMM", "f32")
+    with pytest.raises(ValueError, match="f32rec"):
+        Net(**config.TSH_PARAMS)
+    monkeypatch.setenv("LOOKONCE_GEMM", "f32rec")
+    net = Net(**config.TSH_PARAMS).eval()
+    assert net.gemm_mode == "f32rec"
+    net.gemm_mode = "f32"
+    with pytest.raises(ValueError, match="f32rec"), torch.no_grad():
+        net(torch.zeros(1, 2, 4000), torch.zeros(1, 1, 256))      # refused before any library / device is touched

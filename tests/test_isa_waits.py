@@ -11,7 +11,29 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
-pytestmark = pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not found")
+
+
+def _missing_tools():
+    import isa_waits
+    try:
+        return [n for n, t in zip(("hipcc", "clang-offload-bundler", "llvm-objdump"), isa_waits.tools()) if t is None]
+    except Exception as e:            # no llvm directory at all
+        return [repr(e)]
+
+
+pytestmark = pytest.mark.skipif(bool(_missing_tools()), reason=f"toolchain pieces not found: {_missing_tools()}")
+
+
+def _known_compiler():
+    """The position windows below were read off the code ROCm 7.2's hipcc emits; another compiler may schedule differently
+    (the assertions then report, they do not fail the suite)."""
+    import isa_waits
+    import subprocess
+    try:
+        v = subprocess.check_output([isa_waits.tools()[0], "--version"], text=True)
+    except Exception:
+        return False
+    return "HIP version: 7.2" in v
 
 
 @pytest.fixture(scope="module")
@@ -27,6 +49,8 @@ def isa():
 
 def test_no_serialised_load_store_rounds_in_the_embedder_kernels(isa):
     isa_waits, out = isa
+    if not _known_compiler():
+        pytest.xfail("instruction windows calibrated on ROCm 7.2's hipcc")
     for name, ins in out["lh_embed.hip"].items():
         _, serial = isa_waits.scan(ins, 25)
         assert serial < 3, f"{name}: {serial} rounds of load -> vmcnt(0) -> store (a store loop serialised against its loads)"
@@ -36,6 +60,8 @@ def test_attention_value_refill_stays_in_flight(isa):
     """k_local_attn<3, 2, 40> (the batch-32 shape): behind the prologue (the first 10 % of the instructions) no wait may name a
     load issued fewer than 8 instructions earlier, except in the last 15 % (the last column group drains by construction)."""
     isa_waits, out = isa
+    if not _known_compiler():
+        pytest.xfail("instruction windows calibrated on ROCm 7.2's hipcc")
     name = next(n for n in out["lh_attn.hip"] if "k_local_attnILi3ELi2ELi40" in n)
     ins = out["lh_attn.hip"][name]
     short, _ = isa_waits.scan(ins, 8)
