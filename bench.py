@@ -687,6 +687,35 @@ def secondary_measurements(net, dev, mix8, emb8):
             net.gemm_mode = "f16x3"
             net._ws.clear()
             torch.cuda.empty_cache()
+        # time-axis windows of ONE batch on K streams (Net.time_chunks): same-process A/B over K, each
+        # forward held bit for bit against the whole-clip one
+        try:
+            B = 32
+            mix = mix8.repeat(4, 1, 1).contiguous()
+            emb = emb8.repeat(4, 1, 1).contiguous()
+            keep = net.time_chunks
+            tab = {}
+            net.time_chunks = 1
+            y1 = net(mix, emb).clone()
+            for K in (1, 2, 3, 4, 1):
+                net.time_chunks = K
+                same = bool(torch.equal(net(mix, emb), y1))
+                ms = _time_forward(lambda: net(mix, emb), 10, 3)
+                tab.setdefault(str(K), []).append(ms)
+                log(f"offline B=32 time_chunks={K}: {ms:.3f} ms, bit-identical to the whole clip: {same}")
+                tab[f"{K}_bit_identical"] = same
+            net.time_chunks = keep
+            out["offline_b32_time_chunks"] = {"ms_per_step_by_chunks": {k: v for k, v in tab.items() if not k.endswith("identical")},
+                                              "bit_identical_to_whole_clip": {k[:-14]: v for k, v in tab.items() if k.endswith("identical")},
+                                              "default_time_chunks": keep,
+                                              "workload": "the headline batch (ONE batch in flight) with the time axis cut into K "
+                                                          "windows on K HIP streams; forward only (no metric sums), 10 steps each, "
+                                                          "K = 1 measured first and last"}
+            del y1, mix, emb
+        except Exception as e:
+            out["offline_b32_time_chunks"] = {"error": repr(e)[:200]}
+        net._ws.clear()
+        torch.cuda.empty_cache()
         # two batches in flight (context for DESIGN.md §11, NOT the headline): two Net replicas with the same weights on two HIP
         # streams, steps alternating — what the CUs the inter LSTM leaves idle (194 of 256 busy) are worth to a caller that has
         # the next batch ready.  ms = wall / batches: an inverse throughput, not a latency.
@@ -902,6 +931,8 @@ def main():
     ap.add_argument("--no-gpu-library-baseline", action="store_true",
                     help="skip the reference-ATen-sequence-on-this-GPU context leg (PyTorch-ROCm libraries)")
     ap.add_argument("--rir-len", type=int, default=256, help="--mode render: taps per impulse response")
+    ap.add_argument("--time-chunks", type=int, default=None,
+                    help="override Net.time_chunks: windows of the time axis run on as many HIP streams (A/B runs; 1 = off)")
     ap.add_argument("--tune", default="", help="comma list key=value for lh_set_tuning (A/B runs), e.g. 0=2,1=1")
     args = ap.parse_args()
 
@@ -941,6 +972,8 @@ def main():
     net = net.to(dev)
     if args.gemm:
         net.gemm_mode = args.gemm
+    if args.time_chunks is not None:
+        net.time_chunks = args.time_chunks
 
     if args.mode == "stream":
         return bench_stream(args, net, dev, rank, world)
@@ -1089,7 +1122,9 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: {B} x 5 s 16 kHz binaural clips per GPU, offline forward "
                                    f"(configs/tsh.json separator, random-init weights)",
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"utterance-dp{world}",
-                       "gemm_mode": net.gemm_mode, "tune": args.tune},
+                       "gemm_mode": net.gemm_mode, "tune": args.tune,
+                       "time_chunks": net._n_time_chunks(B, FRAMES_PER_CLIP, 1 if net.gemm_mode == "f16x3" else 0),
+                       "batches_in_flight": 1},
             "whole_path": {"algorithmic_tflops": FLOPS_PER_CLIP * total_clips / elapsed / 1e12,
                            "algorithmic_hbm_gbs": (BYTES_PER_CLIP * B + WEIGHT_BYTES) * world * args.steps / elapsed / 1e9,
                            "frac_hbm_peak": (BYTES_PER_CLIP * B + WEIGHT_BYTES) * world * args.steps / elapsed / 1e9 / (PEAK_HBM_GBS * world)},

@@ -261,6 +261,39 @@ int lh_deconv_istft(const float* y, const float* deconv_buf_in, float* deconv_bu
                     float* istft_buf_out, const void* wdec_pk, const float* bdec, const void* wfb_dec,
                     float* wave_out, unsigned* range_flag, int keep_nonfinite, int B, int T, lh_stream_t stream);
 
+/* ---- time windows (ABI 14) ------------------------------------------------------------------------------------------------
+ * Every stage of a GridNetBlock is causal in time (tfgridnet_causal.py:489-590): the intra pass is per frame, the inter LSTM
+ * carries (h, c) (:521-532), the attention sees the 49 previous K / V rows (:553-562) and the frame stages are per frame.  The
+ * `_win` entry points run the SAME kernels on frames [t0, t0 + Tc) of every utterance of buffers laid out for T frames
+ * ([B][T][97][64] activations, q [4B][T][..], kx / vx [4B][T + 49 + PAD][..]); `lh_X(..., B, T, s)` is `lh_X_win(..., B, T, 0,
+ * T, s)`.  A host can then cut the time axis and run block i on window k + 1 beside block i + 1 on window k on separate
+ * streams (lookoncetohear_amd/net.py, `Net.time_chunks`): the inter LSTM's 625-step dependent chain, which fills only 194 of
+ * the 256 CUs, overlaps with the other stages.  State hand-over between windows of one block, all on the device:
+ *   lh_inter_block_win   (hN, cN) of window k are (h0, c0) of window k + 1 (distinct buffers per window).  `carry`: bit 0 =
+ *                        c0 holds the kernel's internal cell state (-2 log2(e) c, written by the previous window with bit 1),
+ *                        bit 1 = cN is written in that form; 0 = both are the reference's c (tfgridnet_causal.py:526-532).  With
+ *                        the inner boundaries carried in the internal form the windows reproduce the whole-clip launch bit
+ *                        for bit (c / k followed by k * c is two roundings);
+ *   lh_qkv_proj_ln_win   writes rows 49 + t of kx / vx, lh_local_attn_win of window k + 1 reads rows t0 .. of the same
+ *                        buffers: the history IS the previous window's rows, nothing is packed or unpacked.  (Attention tiles
+ *                        read — never need — up to 47 rows past the window: they must hold finite values, e.g. the zeros of the
+ *                        allocation or an earlier forward's rows.)
+ * Tc >= 2 for lh_inter_block_win; t0 + Tc <= T. */
+int lh_intra_block_win(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                       float* out, int B, int T, int t0, int Tc, lh_stream_t stream);
+int lh_inter_block_win(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
+                       const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T, int t0, int Tc,
+                       int carry, lh_stream_t stream);
+int lh_qkv_proj_ln_win(const float* y, const void* w_pk, const float* bias, const float* slopes, const float* lnq_w,
+                       const float* lnq_b, const float* lnk_w, const float* lnk_b, const float* lnv_w,
+                       const float* lnv_b, void* q, void* kx, void* vx, const int* ring_pos, int B, int T, int t0, int Tc,
+                       lh_stream_t stream);
+int lh_local_attn_win(const void* q, const void* kx, const void* vx, float* merged, int B, int T, int t0, int Tc,
+                      lh_stream_t stream);
+int lh_proj_ln_res_win(const float* merged, const void* w_pk, const float* bias, const float* slope, const float* ln_w,
+                       const float* ln_b, const float* y2, const float* gain, float* out, int B, int T, int t0, int Tc,
+                       lh_stream_t stream);
+
 /* ---- plain-fp32 reference kernels of the frame stages (gemm_mode "f32all"; lh_ref32.hip) ----------------------------------
  * The product frame kernels above are split-precision (fp16 hi + lo, ~22 bits) in EVERY arithmetic mode; with these and the
  * exact fp32-MFMA recurrences (lh_ln_lstm_intra / _inter in LH_GEMM_F32) a forward exists whose every contraction is an

@@ -11,7 +11,7 @@ from ctypes import c_int, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "_lookonce_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _P, _I = c_void_p, c_int
 # name -> argtypes; mirrors include/lookonce_hip.h one to one (tests/test_cabi_symbols.py checks both ways)
@@ -35,6 +35,12 @@ SIGNATURES = {
     "lh_ring_advance": [_P, _I, _P],
     "lh_proj_ln_res": [_P] * 9 + [_I, _I, _P],
     "lh_deconv_istft": [_P] * 10 + [_I, _I, _I, _P],
+    # time windows (ABI 14): the five block stages on frames [t0, t0 + Tc) of [B][T][97][64] buffers (net.py `time_chunks`)
+    "lh_intra_block_win": [_P] * 6 + [_I, _I, _I, _I, _P],
+    "lh_inter_block_win": [_P] * 10 + [_I, _I, _I, _I, _I, _P],
+    "lh_qkv_proj_ln_win": [_P] * 14 + [_I, _I, _I, _I, _P],
+    "lh_local_attn_win": [_P] * 4 + [_I, _I, _I, _I, _P],
+    "lh_proj_ln_res_win": [_P] * 9 + [_I, _I, _I, _I, _P],
     "lh_emb_frontend": [_P] * 10 + [_I, _I, _I, _P],
     "lh_emb_axis_fused": [_P] * 8 + [_I, _I, _I, _I, _I, _P],
     "lh_emb_attn_block": [_P] * 24 + [_I, _I, _P],

@@ -42,7 +42,7 @@ __device__ unsigned long long lh_attn_trace_buf[16];
 template <int MQ, int RING, int TQ = 16 * MQ>
 __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restrict__ q, const _Float16* __restrict__ kx,
                                                        const _Float16* __restrict__ vx, float* __restrict__ merged,
-                                                       int BH, int T, int ntt) {
+                                                       int BH, int T, int ntt, int tw0, int tend) {
     // TQ query frames per workgroup in MQ MFMA row tiles (TQ = 16 MQ, or 40 in 3 tiles: 625 frames are then 16 tiles
     // per (batch, head), 2048 workgroups at batch 32 = exactly four rounds of the 512 resident workgroups)
     constexpr int NKEYS = TQ + HIST;           // key rows they can see (65 / 81 / 89)
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
     // XCD-aware placement: the tiles of (batch, head) bh all run on XCD bh % 8
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
     const int bh = (kk / ntt) * 8 + xcd;
-    const int t0 = (kk % ntt) * TQ;
+    const int t0 = tw0 + (kk % ntt) * TQ;        // time window [tw0, tend) of the T frames (lh_local_attn_win; whole clip: 0, T)
     if (bh >= BH) return;
     const long TKP = T + HIST + KV_PAD;
     const _Float16* qb = q + (long)bh * T * LDQKH;
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
             for (int d = 0; d < ND; ++d) am[mq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
         int qoff[MQ], koff[NKT];
 #pragma unroll
-        for (int mq = 0; mq < MQ; ++mq) qoff[mq] = min(t0 + mq * 16 + l15, T - 1) * LDQKH + g4 * 16;
+        for (int mq = 0; mq < MQ; ++mq) qoff[mq] = min(t0 + mq * 16 + l15, tend - 1) * LDQKH + g4 * 16;
 #pragma unroll
         for (int nt = 0; nt < NKT; ++nt) koff[nt] = (nt * 16 + l15) * LDQKH + g4 * 16;
         constexpr int NIT = (AT_KSTEPS + 3) / 4;       // 5 (wave 3 runs 4)
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256, 2) k_local_attn(const _Float16* __restric
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int t = t0 + mq * 16 + g4 * 4 + r;
-                        if (t < T && (TQ == 16 * MQ || mq * 16 + g4 * 4 + r < TQ))      // head-major slab [b][t][hd][f][v]: one head's frame is 6208 contiguous bytes
+                        if (t < tend && (TQ == 16 * MQ || mq * 16 + g4 * 4 + r < TQ))      // head-major slab [b][t][hd][f][v]: one head's frame is 6208 contiguous bytes
                             *reinterpret_cast<float4*>(&merged[(((long)b * T + t) * NH + hd) * DV + col]) =
                                 make_float4(am[mq][0][r], am[mq][1][r], am[mq][2][r], am[mq][3][r]);
                     }
@@ -358,10 +358,15 @@ int attn_set_mq(int v) {
 
 }  // namespace lh
 
-extern "C" int lh_local_attn(const void* q, const void* kx, const void* vx, float* merged, int B, int T,
-                             lh_stream_t stream) {
+extern "C" int lh_local_attn_win(const void* q, const void* kx, const void* vx, float* merged, int B, int T, int t0, int Tc,
+                                 lh_stream_t stream) {
     using namespace lh;
-    if (!q || !kx || !vx || !merged || B <= 0 || T <= 0) return LH_ERR_ARG;
+    if (!q || !kx || !vx || !merged || B <= 0 || T <= 0 || t0 < 0 || Tc <= 0 || t0 + Tc > T) return LH_ERR_ARG;
+    const int Tfull = T;
+    // tile shape from the WHOLE clip (a window then cuts the time axis into the same tiles as the whole-clip launch when t0
+    // is a multiple of the tile length: bit-identical outputs); tile count and bounds from the window
+    const int Tshape = T;
+    T = Tc;
     const int BH = B * NH;
     const int bh8 = (BH + 7) / 8 * 8;
     // Query frames per workgroup: one 16-frame tile when the clip is that short (streaming: T = 1); two tiles share
@@ -371,20 +376,25 @@ extern "C" int lh_local_attn(const void* q, const void* kx, const void* vx, floa
     // launch is latency-bound and the shorter workgroup wins.  The V ring is two-deep: a three-deep one (228 registers
     // since the single-accumulator split) measured 3 % slower.
     int mq = g_attn_mq;
-    if (T <= 16) mq = 1;
-    else if (mq == 0) mq = (long)bh8 * ((T + 31) / 32) > 512 ? 3 : 2;
+    if (Tshape <= 16) mq = 1;
+    else if (mq == 0) mq = (long)bh8 * ((Tshape + 31) / 32) > 512 ? 3 : 2;
     const int tq = mq == 3 ? 40 : 16 * mq;
     const int ntt = (T + tq - 1) / tq;
     // latency-bound launches (a handful of workgroups): split the V columns of a tile over 7 workgroups
     const dim3 grid(bh8 * ntt, bh8 * ntt <= 64 ? 7 : 1);
     const _Float16 *qh = (const _Float16*)q, *kh = (const _Float16*)kx, *vh = (const _Float16*)vx;
     if (mq == 1)
-        hipLaunchKernelGGL((k_local_attn<1, 3>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
+        hipLaunchKernelGGL((k_local_attn<1, 3>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, Tfull, ntt, t0, t0 + Tc);
     else if (mq == 3)
-        hipLaunchKernelGGL((k_local_attn<3, 2, 40>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
+        hipLaunchKernelGGL((k_local_attn<3, 2, 40>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, Tfull, ntt, t0, t0 + Tc);
     else
-        hipLaunchKernelGGL((k_local_attn<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, T, ntt);
+        hipLaunchKernelGGL((k_local_attn<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, qh, kh, vh, merged, BH, Tfull, ntt, t0, t0 + Tc);
     return check_launch();
+}
+
+extern "C" int lh_local_attn(const void* q, const void* kx, const void* vx, float* merged, int B, int T,
+                             lh_stream_t stream) {
+    return lh_local_attn_win(q, kx, vx, merged, B, T, 0, T, stream);
 }
 
 extern "C" int lh_ring_pack(const float* k_buf, const float* v_buf, void* kx, void* vx, int B, int T,

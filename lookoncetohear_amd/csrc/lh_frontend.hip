@@ -281,7 +281,7 @@ extern "C" int lh_embed_proj_ln(const float* emb, const float* w, const float* b
     return check_launch();
 }
 
-extern "C" int lh_abi_version(void) { return 13; }
+extern "C" int lh_abi_version(void) { return 14; }
 
 extern "C" int lh_check_config(int nfft, int hop, int n_mics, int emb_dim, int n_blocks_unused, int lstm_hidden,
                                int n_heads, int attn_window, int n_srcs, int spk_emb_dim) {

@@ -1046,7 +1046,7 @@ int launch_intra_xp(const float* x, const void* w_pk, const float* b_sum, const 
 int xp_set(int key, int v);
 int launch_inter_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                     const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep, int sdiv, int so,
-                    int si, int ps, hipStream_t st);
+                    int si, int ps, hipStream_t st, int cflags = 0);
 }
 namespace lh { int backend_set_runs(int v); } // lh_backend.hip
 #if defined(LH_PROBE_TRACE)
@@ -1152,6 +1152,35 @@ extern "C" int lh_intra_block(const float* x, const void* w_pk, const float* b_s
             rc = launch_intra_xp(x, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, out, n_frames,
                                  NF, 1, NF, 0, 1, dir, dir, st);
     return rc;
+}
+
+// Time windows (ABI 14): the same fused stages on frames [t0, t0 + Tc) of every utterance of [B][T][97][64] buffers — the
+// causal structure of the block (tfgridnet_causal.py:505-538: the intra pass is per frame, the inter pass carries (h, c))
+// lets a host cut the time axis and run block i on window k+1 beside block i+1 on window k (net.py `time_chunks`).
+extern "C" int lh_intra_block_win(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk,
+                                  const float* blin, float* out, int B, int T, int t0, int Tc, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !w_pk || !b_sum || !wlin_pk || !blin || !out || B <= 0 || T <= 0 || x == out || t0 < 0 || Tc <= 0 || t0 + Tc > T)
+        return LH_ERR_ARG;
+    // sequence s = (b, j): row base (b * T + t0 + j) * 97, step = frequency bin
+    const long off = (long)t0 * NF * C;
+    int rc = LH_OK;
+    for (int dir = 0; dir < 2 && rc == LH_OK; ++dir)
+        rc = launch_intra_xp(x + off, w_pk, b_sum, (const _Float16*)wlin_pk + (long)dir * 4 * 2 * 64 * 16, blin, out + off,
+                             B * Tc, NF, Tc, T * NF, NF, 1, dir, dir, (hipStream_t)stream);
+    return rc;
+}
+
+extern "C" int lh_inter_block_win(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk,
+                                  const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out,
+                                  int B, int T, int t0, int Tc, int carry, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !w_pk || !b_sum || !wlin_pk || !blin || !h0 || !c0 || !hN || !cN || !out || B <= 0 || T <= 0) return LH_ERR_ARG;
+    if (h0 == hN || c0 == cN || x == out || t0 < 0 || Tc < 2 || t0 + Tc > T || (carry & ~3)) return LH_ERR_ARG;
+    // sequence s = b*97 + f; step j = frame t0 + j; row(s, j) = (b*T + t0 + j)*97 + f
+    const long off = (long)t0 * NF * C;
+    return launch_inter_xp(x + off, w_pk, b_sum, wlin_pk, blin, h0, c0, hN, cN, out + off, B * NF, Tc, NF, T * NF, 1, NF,
+                           (hipStream_t)stream, carry);
 }
 
 extern "C" int lh_inter_block(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk,

@@ -182,7 +182,10 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
                                                      const float* __restrict__ lnv_w, const float* __restrict__ lnv_b,
                                                      _Float16* __restrict__ q, _Float16* __restrict__ kx,
                                                      _Float16* __restrict__ vx, int T, int nframes,
-                                                     const int* __restrict__ ring_pos) {
+                                                     const int* __restrict__ ring_pos, int Tc, int tw0) {
+    // time window (lh_qkv_proj_ln_win): frame index fr of the launch = (b, j), j < Tc, is frame t = tw0 + j of utterance b in
+    // buffers of T frames; the whole-clip launch is Tc = T, tw0 = 0
+    auto gidx = [&](int fr) -> long { return (long)(fr / Tc) * T + tw0 + fr % Tc; };
     __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float yf[Y_N];
@@ -214,19 +217,19 @@ __global__ void __launch_bounds__(256, 2) k_qkv_proj_ln(const float* __restrict_
     for (int i = tid; i < 2 * NH * (YQS - DQK); i += 256)      // pad entries 582.. of the Q / K heads stay zero
         yf[(i / (YQS - DQK)) * YQS + DQK + i % (YQS - DQK)] = 0.f;
     float4 stg[FR_NLD];
-    if ((int)blockIdx.x < nframes) frame_load(y + (long)blockIdx.x * NF * C, tid, stg);
+    if ((int)blockIdx.x < nframes) frame_load(y + gidx(blockIdx.x) * NF * C, tid, stg);
     const long tkp = T + HIST + KV_PAD;
     // K / V row of frame t: HIST + t behind the history rows — or, for a one-frame chunk on a persistent ring
     // (ring_pos != NULL, T = 1), slot (*ring_pos mod 50): the 50 rows are then exactly the attention window, in
     // rotated order, which softmax and P.V do not care about
     const int krow0 = ring_pos ? (int)((unsigned)*ring_pos % (unsigned)WIN) : HIST;   // unsigned: never before the ring
     for (int fr = blockIdx.x; fr < nframes; fr += gridDim.x) {      // grid-stride over frames (b*T + t)
-        const int b = fr / T, t = fr % T;
+        const int b = fr / Tc, t = tw0 + fr % Tc;
         QKV_STAMP(0);
         frame_store_scaled(ahi, alo, rinv, tid, stg);
         __syncthreads();                      // image complete; also orders the previous frame's reads of `yf`
         QKV_STAMP(1);
-        if (fr + (int)gridDim.x < nframes) frame_load(y + (long)(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
+        if (fr + (int)gridDim.x < nframes) frame_load(y + gidx(fr + gridDim.x) * NF * C, tid, stg);   // prefetch
 
         // row tiles 0..5 hold rows 0..95 (all valid); only tile 6 (rows 96..111, one valid) needs the bounds check.
         // Round 5 (the kernel is VALU-bound): one accumulator chain per tile (no am + ac adds) and PReLU
@@ -321,8 +324,9 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
                                                      const float* __restrict__ bias, const float* __restrict__ slope,
                                                      const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                      const float* __restrict__ y2, const float* __restrict__ gain,
-                                                     float* __restrict__ out, int T, int nframes) {
+                                                     float* __restrict__ out, int T, int nframes, int Tc, int tw0) {
     constexpr int YP = C + 4;
+    auto gidx = [&](int fr) -> long { return (long)(fr / Tc) * T + tw0 + fr % Tc; };      // time window, see k_qkv_proj_ln
     __shared__ __attribute__((aligned(16))) _Float16 ahi[FR_A];
     __shared__ __attribute__((aligned(16))) _Float16 alo[FR_A];
     __shared__ __attribute__((aligned(16))) float ys[NF * YP];
@@ -346,13 +350,13 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
 
     frame_zero_pad(ahi, alo, tid);
     float4 stg[FR_NLD];
-    if ((int)blockIdx.x < nframes) frame_load_heads(merged + (long)blockIdx.x * N, tid, stg);
+    if ((int)blockIdx.x < nframes) frame_load_heads(merged + gidx(blockIdx.x) * N, tid, stg);
     for (int fidx = blockIdx.x; fidx < nframes; fidx += gridDim.x) {     // grid-stride over frames (b*T + t)
-        const int b = fidx / T;
-        const long fr = (long)fidx * N;
+        const int b = fidx / Tc;
+        const long fr = gidx(fidx) * N;
         frame_store(ahi, alo, tid, stg);
         __syncthreads();                      // image complete; also orders the previous frame's reads of `ys`
-        if (fidx + (int)gridDim.x < nframes) frame_load_heads(merged + (long)(fidx + gridDim.x) * N, tid, stg);
+        if (fidx + (int)gridDim.x < nframes) frame_load_heads(merged + gidx(fidx + gridDim.x) * N, tid, stg);
 
         // residual rows of this frame: loads in flight during the MFMA + statistics phases
         float4 rv[NSLOT];
@@ -462,30 +466,46 @@ extern "C" int lh_linear_res(const float* h, const void* w_pk, const float* bias
     return check_launch();
 }
 
+extern "C" int lh_qkv_proj_ln_win(const float* y, const void* w_pk, const float* bias, const float* slopes,
+                                  const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                                  const float* lnv_w, const float* lnv_b, void* q, void* kx, void* vx, const int* ring_pos,
+                                  int B, int T, int t0, int Tc, lh_stream_t stream) {
+    using namespace lh;
+    if (!y || !w_pk || !bias || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !q || !kx ||
+        !vx || B <= 0 || T <= 0 || (ring_pos && T != 1) || t0 < 0 || Tc <= 0 || t0 + Tc > T)
+        return LH_ERR_ARG;
+    const int nframes = B * Tc;
+    hipLaunchKernelGGL(k_qkv_proj_ln, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y,
+                       (const _Float16*)w_pk, bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, (_Float16*)q,
+                       (_Float16*)kx, (_Float16*)vx, T, nframes, ring_pos, Tc, t0);
+    return check_launch();
+}
+
 extern "C" int lh_qkv_proj_ln(const float* y, const void* w_pk, const float* bias, const float* slopes,
                               const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
                               const float* lnv_w, const float* lnv_b, void* q, void* kx, void* vx, const int* ring_pos,
                               int B, int T, lh_stream_t stream) {
+    return lh_qkv_proj_ln_win(y, w_pk, bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, q, kx, vx, ring_pos, B, T, 0, T,
+                              stream);
+}
+
+extern "C" int lh_proj_ln_res_win(const float* merged, const void* w_pk, const float* bias, const float* slope,
+                                  const float* ln_w, const float* ln_b, const float* y2, const float* gain, float* out,
+                                  int B, int T, int t0, int Tc, lh_stream_t stream) {
     using namespace lh;
-    if (!y || !w_pk || !bias || !slopes || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !lnv_w || !lnv_b || !q || !kx ||
-        !vx || B <= 0 || T <= 0 || (ring_pos && T != 1))
+    if (!merged || !w_pk || !bias || !slope || !ln_w || !ln_b || !y2 || !out || B <= 0 || T <= 0 || t0 < 0 || Tc <= 0 ||
+        t0 + Tc > T)
         return LH_ERR_ARG;
-    const int nframes = B * T;
-    hipLaunchKernelGGL(k_qkv_proj_ln, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, y,
-                       (const _Float16*)w_pk, bias, slopes, lnq_w, lnq_b, lnk_w, lnk_b, lnv_w, lnv_b, (_Float16*)q,
-                       (_Float16*)kx, (_Float16*)vx, T, nframes, ring_pos);
+    const int nframes = B * Tc;
+    hipLaunchKernelGGL(k_proj_ln_res, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, merged,
+                       (const _Float16*)w_pk, bias, slope, ln_w, ln_b, y2, gain, out, T, nframes, Tc, t0);
     return check_launch();
 }
 
 extern "C" int lh_proj_ln_res(const float* merged, const void* w_pk, const float* bias, const float* slope,
                               const float* ln_w, const float* ln_b, const float* y2, const float* gain, float* out,
                               int B, int T, lh_stream_t stream) {
-    using namespace lh;
-    if (!merged || !w_pk || !bias || !slope || !ln_w || !ln_b || !y2 || !out || B <= 0 || T <= 0) return LH_ERR_ARG;
-    const int nframes = B * T;
-    hipLaunchKernelGGL(k_proj_ln_res, dim3(nframes < 512 ? nframes : 512), dim3(256), 0, (hipStream_t)stream, merged,
-                       (const _Float16*)w_pk, bias, slope, ln_w, ln_b, y2, gain, out, T, nframes);
-    return check_launch();
+    return lh_proj_ln_res_win(merged, w_pk, bias, slope, ln_w, ln_b, y2, gain, out, B, T, 0, T, stream);
 }
 
 #if defined(LH_DBG_K6)

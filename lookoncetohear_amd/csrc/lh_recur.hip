@@ -432,7 +432,10 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
                                                      const float* __restrict__ blin, const float* __restrict__ h0,
                                                      const float* __restrict__ c0, float* __restrict__ hN,
                                                      float* __restrict__ cN, float* out, int nseq, int nstep, int sdiv,
-                                                     int so, int si, int ps, int dir, int accumulate, int prio) {
+                                                     int so, int si, int ps, int dir, int accumulate, int prio, int cflags) {
+    // cflags (time windows, lh_inter_block_win `carry`): bit 0 = c0 already holds the kernel's scaled cell state -2 log2(e) c
+    // (written by the previous window with bit 1), bit 1 = cN is written that way — the state then crosses a window boundary
+    // without the two roundings of c / k and k * c, and the windows reproduce the whole-clip launch bit for bit
     constexpr int NS = 16;
     __shared__ __attribute__((aligned(16))) _Float16 ahi[2 * NS * XP_AP];
     __shared__ __attribute__((aligned(16))) _Float16 alo[2 * NS * XP_AP];
@@ -517,11 +520,20 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
         *reinterpret_cast<xp_f16x4*>(&ahi[idx]) = h4;
         *reinterpret_cast<xp_f16x4*>(&alo[idx]) = l4;
     };
+    // the first two rows of a launch, in EXACTLY the arithmetic of the step's row-wise role below (same sums, same fused
+    // operations): a time window (lh_inter_block_win) starts here with rows that the whole-clip launch normalises inside its
+    // loop, and the two must agree bit for bit
     auto norm_store_x = [&](int buf, float4 v) {
-        const float mean = group16_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
-        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-        const float var = group16_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / C);
-        const float rstd = __builtin_amdgcn_rsqf(var + LN_EPS);
+        float s = v.x + v.y, t = v.z + v.w;
+        s += t;
+        s = group16_sum(s);
+        v.x = __builtin_fmaf(s, -1.0f / C, v.x); v.y = __builtin_fmaf(s, -1.0f / C, v.y);
+        v.z = __builtin_fmaf(s, -1.0f / C, v.z); v.w = __builtin_fmaf(s, -1.0f / C, v.w);
+        float qa = v.x * v.x, qb = v.z * v.z;
+        qa = __builtin_fmaf(v.y, v.y, qa); qb = __builtin_fmaf(v.w, v.w, qb);
+        qa += qb;
+        qa = group16_sum(qa);
+        const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qa, 1.0f / C, LN_EPS));
         store_split4(buf * NS * XP_AP + a_row, v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd);
     };
     auto load_row = [&](const char* base, int it) -> float4 {
@@ -562,7 +574,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
         const int s = min(s0 + l15, nseq - 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            creg[m] = c0 ? XP_K2 * c0[(long)s * H + unit0 + m] : 0.0f;
+            creg[m] = c0 ? ((cflags & 1) ? 1.0f : XP_K2) * c0[(long)s * H + unit0 + m] : 0.0f;
             hreg[m] = 0.0f;
         }
     }
@@ -775,7 +787,7 @@ __global__ void __launch_bounds__(512, 1) k_inter_xp(const float* __restrict__ x
     }
     if (cN && s0 + l15 < nseq) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + m] = creg[m] * (1.0f / XP_K2);
+        for (int m = 0; m < 2; ++m) cN[(long)(s0 + l15) * H + unit0 + m] = creg[m] * ((cflags & 2) ? 1.0f : 1.0f / XP_K2);
     }
 }
 
@@ -789,10 +801,11 @@ static int g_xp_prio_inter = 3;   // lh_set_tuning(9, v): k_inter_xp, 0 = none, 
 
 int launch_inter_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                     const float* h0, const float* c0, float* hN, float* cN, float* out, int nseq, int nstep, int sdiv, int so,
-                    int si, int ps, hipStream_t st) {
+                    int si, int ps, hipStream_t st, int cflags) {
     if (nstep < 2) return LH_ERR_ARG;             // the first two steps are peeled unconditionally
     hipLaunchKernelGGL(k_inter_xp, dim3((nseq + 15) / 16), dim3(512), 0, st, x, (const _Float16*)w_pk, b_sum,
-                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, 0, 0, g_xp_prio_inter);
+                       (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, nseq, nstep, sdiv, so, si, ps, 0, 0, g_xp_prio_inter,
+                       cflags);
     return check_launch();
 }
 int xp_set(int key, int v) {

@@ -118,6 +118,37 @@ class _TFGridNetParams(nn.Module):
         self.deconv = nn.ConvTranspose2d(emb_dim, n_srcs * 2, (3, 3), padding=(2, 1))
 
 
+class _Lanes:
+    """K HIP streams forked from and joined to the current stream of `dev` (the windows of `Net.time_chunks`).  The only
+    stream / event calls of the chunked block loop live here; tests/hipemu/hosts.py substitutes a serial stand-in."""
+    serial = False
+
+    def __init__(self, dev, streams):
+        self.dev, self.streams = dev, streams
+        self.main = torch.cuda.current_stream(dev)
+
+    def fork(self):
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        for s_ in self.streams:
+            s_.wait_event(ev)
+
+    def on(self, k):
+        return torch.cuda.stream(self.streams[k])
+
+    def signal(self, k):
+        ev = torch.cuda.Event()
+        ev.record(self.streams[k])
+        return ev
+
+    def wait(self, k, ev):
+        self.streams[k].wait_event(ev)
+
+    def join(self):
+        for s_ in self.streams:
+            self.main.wait_stream(s_)
+
+
 class Net(_cabi.HipHost, nn.Module):
     _host_name = "Net"
 
@@ -177,6 +208,15 @@ class Net(_cabi.HipHost, nn.Module):
         self.fuse_intra_min_frames = 8192
         self.inter_matvec_max_seqs = 512        # inter LSTM: per-sequence workgroups up to two rounds of CUs (batch <= 5)
         self.stream_intra_max_frames = 128      # up to here one workgroup per (frame, direction) still finds its own CU
+        # time-axis pipelining of the three blocks (round 6; include/lookonce_hip.h "time windows"): every stage is causal in
+        # t, so with time_chunks = K > 1 the frames are cut into K windows, window k on its own HIP stream, and block i on
+        # window k + 1 runs beside block i + 1 on window k — the inter LSTM (a 625-step dependent chain on 194 of the 256 CUs)
+        # overlaps with the other stages of the SAME batch.  State is handed over on the device: (h, c) per window, the K / V
+        # history = the previous window's rows of the history-extended buffers (one pair per block, so a window that runs
+        # ahead cannot overwrite rows a slower one still reads).  1 = off.  LOOKONCE_TIME_CHUNKS overrides.
+        self.time_chunks = int(os.environ.get("LOOKONCE_TIME_CHUNKS", "1"))
+        self.chunk_min_frames = 64              # >= the 49 frames of attention history: a window then depends on ONE predecessor
+        self._chunk_streams: Dict[tuple, list] = {}
         self._pack_key = None
         self._packed = None
         self._ws: Dict[tuple, dict] = {}
@@ -394,17 +434,18 @@ class Net(_cabi.HipHost, nn.Module):
 
             class _Timed:                       # HIP events on the launch stream around each C-ABI call
                 @staticmethod
-                def call(name, *args):
+                def call(fn, *args):
+                    name = fn[:-4] if fn.endswith("_win") else fn       # a windowed call counts as its stage
                     if prof is None or (only is not None and name not in only):
-                        return lib_.call(name, *args)
+                        return lib_.call(fn, *args)
                     if stride > 1:                  # sampled bracket: an event record costs ~6 us of stream time
                         n = count.get(name, 0)
                         count[name] = n + 1
                         if n % stride:
-                            return lib_.call(name, *args)
+                            return lib_.call(fn, *args)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    lib_.call(name, *args)
+                    lib_.call(fn, *args)
                     e1.record()
                     prof.append((name, e0, e1))
 
@@ -421,7 +462,10 @@ class Net(_cabi.HipHost, nn.Module):
             rows = Bn * T * F_
             mode = 1 if self.gemm_mode == "f16x3" else 0
             wkey, bkey = ("_w16", "_b16") if mode else ("_w", "_b")
-            for i in range(self.n_blocks):
+            K = self._n_time_chunks(Bn, T, mode)
+            if K > 1:
+                self._blocks_chunked(lib, pk, ws, state, Bn, T, dev, from_zero, want_state, K)
+            for i in range(self.n_blocks if K == 1 else 0):
                 bp = pk["blocks"][i]
                 bs = state["gridnet_bufs"][f"buf{i}"]
                 h0, c0 = c32(bs["h0"]), c32(bs["c0"])
@@ -500,6 +544,115 @@ class Net(_cabi.HipHost, nn.Module):
                 if self.range_status(dev):
                     raise RuntimeError(self._RANGE_MSG.format("this forward"))
         return y, (state if want_state else None)
+
+    def _n_time_chunks(self, Bn: int, T: int, mode: int) -> int:
+        """Windows the block loop is cut into: `time_chunks`, when the batch runs the fused batch kernels (the windowed entry
+        points are theirs) and every window keeps at least the 49 frames of attention history (a window then only depends on
+        its predecessor); 1 otherwise (small batches, streaming, taps, exact-fp32 modes)."""
+        K = int(self.time_chunks)
+        if K <= 1 or mode != 1 or not self.fuse_linear or self._debug_taps is not None:
+            return 1
+        if Bn * self.n_freqs <= self.inter_matvec_max_seqs:
+            return 1
+        K = min(K, T // max(self.chunk_min_frames, 1))
+        while K > 1 and Bn * (T // K) < self.fuse_intra_min_frames // 2:
+            K -= 1
+        return max(K, 1)
+
+    def _window_bounds(self, Bn: int, T: int, K: int) -> list:
+        """Window boundaries [0, ..., T]: even cuts, moved to multiples of the attention kernel's query-tile length (40 frames
+        once the whole-clip launch exceeds 512 workgroups, else 32: lh_attn.hip `lh_local_attn_win`) when the windows are long
+        enough — the windows then cut the time axis into exactly the tiles of the whole-clip launch and the forward is
+        bit-identical to the unchunked one (every other stage is per frame or per sequence)."""
+        bh8 = (Bn * self.n_head + 7) // 8 * 8
+        align = 40 if bh8 * ((T + 31) // 32) > 512 else 32
+        cuts = [(k * T) // K for k in range(K + 1)]
+        if T // K >= 2 * align:
+            cuts = [0] + [int(round(k * T / K / align)) * align for k in range(1, K)] + [T]
+        return cuts
+
+    def _lanes(self, dev, K) -> _Lanes:
+        key = (str(dev), K)
+        if key not in self._chunk_streams:
+            self._chunk_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        if self.chunk_min_frames < self.local_atten_len - 1:
+            raise ValueError("chunk_min_frames must cover the attention history (49 frames) on concurrent streams")
+        return _Lanes(dev, self._chunk_streams[key])
+
+    def _blocks_chunked(self, lib, pk, ws, state, Bn, T, dev, from_zero, want_state, K):
+        """The three GridNet blocks (tfgridnet_causal.py:489-590) with the time axis cut into K windows, window k on stream k:
+        for block i and window k the five stage launches of `_separate` through the `_win` entry points, with two cross-stream
+        dependences per (block, window) — the inter LSTM's (h, c) and the K / V rows of the previous window."""
+        F_, nh, hist = self.n_freqs, self.n_head, self.local_atten_len - 1
+        P = lambda t: t.data_ptr()
+        c32 = lambda t: t.contiguous().float()
+        xa, xb, xc = ws["xa"], ws["xb"], ws["xc"]
+        lanes = self._lanes(dev, K)
+        if "kxb" not in ws:                                   # one history-extended K / V pair per block
+            z16 = lambda *s_: torch.zeros(*s_, device=dev, dtype=torch.float16)
+            ws["kxb"] = [ws["kx"]] + [z16(*ws["kx"].shape) for _ in range(self.n_blocks - 1)]
+            ws["vxb"] = [ws["vx"]] + [z16(*ws["vx"].shape) for _ in range(self.n_blocks - 1)]
+            ws["hist_dirty_b"] = [False] * self.n_blocks
+        bounds = self._window_bounds(Bn, T, K)
+        # per block: (h, c) of every window boundary; history rows in place (on the current stream, before the fork)
+        hs, cs = [], []
+        for i in range(self.n_blocks):
+            bs = state["gridnet_bufs"][f"buf{i}"]
+            h0, c0 = c32(bs["h0"]).reshape(-1, self.hidden), c32(bs["c0"]).reshape(-1, self.hidden)
+            hs.append([h0] + [torch.empty_like(h0) for _ in range(K)])
+            cs.append([c0] + [torch.empty_like(c0) for _ in range(K)])
+            kx, vx = ws["kxb"][i], ws["vxb"][i]
+            if not from_zero:
+                lib.call("lh_ring_pack", P(c32(bs["K_buf"])), P(c32(bs["V_buf"])), P(kx), P(vx), Bn, T, self._stream(dev))
+                ws["hist_dirty_b"][i] = True
+                if i == 0:
+                    ws["hist_dirty"] = True                   # block 0's pair is the unchunked path's one pair
+            elif ws["hist_dirty_b"][i] or (i == 0 and ws["hist_dirty"]):
+                kx[:, :hist].zero_()
+                vx[:, :hist].zero_()
+                ws["hist_dirty_b"][i] = False
+                if i == 0:
+                    ws["hist_dirty"] = False
+        lanes.fork()
+        for i in range(self.n_blocks):
+            bp = pk["blocks"][i]
+            kx, vx = ws["kxb"][i], ws["vxb"][i]
+            gain = ws["gain"] if (i == 0 and self.n_blocks > 1) else None
+            ev_r = ev_q = None                                # the previous window's (h, c) / K, V rows of THIS block
+            for k in range(K):
+                t0, Tc = bounds[k], bounds[k + 1] - bounds[k]
+                with lanes.on(k):
+                    st = self._stream(dev)
+                    lib.call("lh_intra_block_win", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
+                             P(bp["intra_lin_b"]), P(xb), Bn, T, t0, Tc, st)
+                    if k > 0:
+                        lanes.wait(k, ev_r)
+                    lib.call("lh_inter_block_win", P(xb), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
+                             P(bp["inter_lin_b"]), P(hs[i][k]), P(cs[i][k]), P(hs[i][k + 1]), P(cs[i][k + 1]), P(xc), Bn, T, t0,
+                             Tc, (1 if k > 0 else 0) | (2 if k + 1 < K else 0), st)  # inner boundaries: internal cell-state form
+                    if k + 1 < K:
+                        ev_r = lanes.signal(k)
+                    lib.call("lh_qkv_proj_ln_win", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),
+                             P(bp["lnq_b"]), P(bp["lnk_w"]), P(bp["lnk_b"]), P(bp["lnv_w"]), P(bp["lnv_b"]), P(ws["q"]),
+                             P(kx), P(vx), None, Bn, T, t0, Tc, st)
+                    ev_prev = ev_q
+                    if k + 1 < K:
+                        ev_q = lanes.signal(k)
+                    if k > 0:
+                        lanes.wait(k, ev_prev)
+                    lib.call("lh_local_attn_win", P(ws["q"]), P(kx), P(vx), P(xb), Bn, T, t0, Tc, st)
+                    lib.call("lh_proj_ln_res_win", P(xb), P(bp["proj_w"]), P(bp["proj_b"]), P(bp["proj_slope"]),
+                             P(bp["proj_ln_w"]), P(bp["proj_ln_b"]), P(xc), P(gain) if gain is not None else None, P(xa),
+                             Bn, T, t0, Tc, st)
+        lanes.join()
+        if want_state:
+            for i in range(self.n_blocks):
+                bs = state["gridnet_bufs"][f"buf{i}"]
+                bs["h0"], bs["c0"] = hs[i][K].reshape(1, -1, self.hidden), cs[i][K].reshape(1, -1, self.hidden)
+                bs["K_buf"] = torch.empty(Bn * nh, hist, self.E * F_, device=dev, dtype=torch.float32)
+                bs["V_buf"] = torch.empty(Bn * nh, hist, self.V_dim * F_, device=dev, dtype=torch.float32)
+                lib.call("lh_ring_unpack", P(ws["kxb"][i]), P(ws["vxb"][i]), P(bs["K_buf"]), P(bs["V_buf"]), Bn, T,
+                         self._stream(dev))
 
     def _check_gemm_mode(self):
         if self.gemm_mode not in ("f32rec", "f32all", "f16x3"):

@@ -111,6 +111,12 @@ timelines)          # dispatch timelines of one step (scripts/rocpd_summary.py -
     cd $R
     timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
     cut -c1-400 gpurun_out/bench.json; tail -3 gpurun_out/step_timeline_*.txt ;;
+chunks)             # Net.time_chunks: the bit-identity test, then same-box A/B of the default line over K (REPS x K in "1 2 3 4")
+    timeout 600 python -m pytest tests/test_gpu_modes.py -m gpu -x -q -k "time_chunks" 2>&1 | tail -5 | tee gpurun_out/pytest_chunks.txt
+    for rep in $(seq ${REPS:-2}); do for k in ${KS:-1 2 3 4}; do
+        timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-power --no-gpu-library-baseline --time-chunks $k ${BENCH_ARGS:-} > gpurun_out/bench_ab.json 2>> gpurun_out/bench.err
+        bench_line gpurun_out/bench_ab.json "time_chunks $k B=32"
+    done; done | tee gpurun_out/ab_time_chunks.txt ;;
 final)              # A/B of bench.py's event bracket (every call / every 4th call of the dominant entry point), the default line, the
                     # embedder line, the GPU suite, smoke
     for rep in 1 2; do for es in 1 4; do

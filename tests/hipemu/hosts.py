@@ -31,9 +31,24 @@ class EmuHost(_cabi.HipHost):
         return torch.zeros(2, dtype=torch.int32)
 
 
+class SerialLanes:
+    """Stand-in for `net._Lanes` (the K streams of `Net.time_chunks`): the emulator executes every launch at once, in
+    enqueue order — block-major, window-minor, which satisfies every dependence the events express."""
+    serial = True
+
+    def fork(self): pass
+    def on(self, k): return contextlib.nullcontext()
+    def signal(self, k): return None
+    def wait(self, k, ev): pass
+    def join(self): pass
+
+
 class EmuNet(EmuHost, Net):
     def _sync(self, dev):
         pass
+
+    def _lanes(self, dev, K):
+        return SerialLanes()
 
     def _capturing(self):
         return False

@@ -113,6 +113,39 @@ def test_previous_fused_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
     assert (y - yo).abs().max() < TOL
 
 
+def test_time_windows_equal_the_whole_clip(emu_net, oracle_cfg_sd):
+    """`Net.time_chunks` (ABI 14 `_win` entry points): B = 6, T = 7 cut into 3 windows of 2 / 2 / 3 frames — every stage of
+    every block through its windowed launch, (h, c) handed from window to window, the attention of a window reading its
+    history from the previous windows' rows of the per-block K / V buffers, non-zero state in and the next state out — against
+    the whole-clip launches of the same kernels and against the oracle.  (The recurrent stages are bit-identical — the inner
+    boundaries carry the cell state in the kernel's internal form; the attention of these 2-frame windows sums its 50 slots in
+    another tile alignment than the one 16-frame tile of the whole clip, hence 5e-6 here.  Windows that start on a tile
+    boundary reproduce the whole clip bit for bit: tests/test_gpu_modes.py at B = 32.)"""
+    cfg, sd = oracle_cfg_sd
+    B, T = 6, 7
+    d = synth.batch(list(range(20, 20 + B)), 128 * T + 64)
+    st = O.random_state(cfg, B, 13)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    saved = emu_net.fuse_intra_min_frames, emu_net.time_chunks, emu_net.chunk_min_frames
+    emu_net.fuse_intra_min_frames = 1
+    try:
+        y1, s1 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+        emu_net.time_chunks, emu_net.chunk_min_frames = 3, 2
+        assert emu_net._n_time_chunks(B, T, 1) == 3
+        y3, s3 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+        yz = emu_net(d["mixture"], d["embedding_gt"])                 # from the zero state: history rows re-zeroed per block
+    finally:
+        emu_net.fuse_intra_min_frames, emu_net.time_chunks, emu_net.chunk_min_frames = saved
+    assert (y3 - y1).abs().max() < 5e-6 and (y3 - yo).abs().max() < TOL
+    f1, f3, fo = O.flat_state(s1), O.flat_state(s3), O.flat_state(so)
+    for k in fo:
+        assert f3[k].shape == fo[k].shape and (f3[k] - f1[k]).abs().max() < 1e-5 and (f3[k] - fo[k]).abs().max() < TOL, k
+    for k in ("h0", "c0", "K_buf", "V_buf"):                  # block 0 up to its Q / K / V stage: recurrences + frame kernels only
+        assert torch.equal(f3["gridnet_bufs.buf0." + k], f1["gridnet_bufs.buf0." + k]), k
+    yzo = O.forward(cfg, sd, d["mixture"], d["embedding_gt"])
+    assert (yz - yzo).abs().max() < TOL
+
+
 @pytest.mark.parametrize("tune5", [0, 2, (0, 19)], ids=["k_inter_xp", "k_lstm_lin8p", "k_inter_xp-roles-swapped"])
 def test_fused_inter_kernels(emu_net, oracle_cfg_sd, tune5):
     """k_inter_xp (lh_recur.hip, the default) and the previous k_lstm_lin8p (lh_set_tuning(5, 2)): B=6 (582 sequences = 37 tiles, last one ragged; above

@@ -468,3 +468,50 @@ def test_inputs_on_a_non_current_device(oracle_cfg_sd):
     assert torch.cuda.current_device() == 0
     y1 = n1(d["mixture"].to("cuda:1"), d["embedding_gt"].to("cuda:1"))
     assert torch.equal(y0.cpu(), y1.cpu())
+
+
+def test_time_chunks_are_bit_identical_to_the_whole_clip(nets, oracle_cfg_sd):
+    """`Net.time_chunks` (ABI 14 `_win` entry points): the headline shape — 32 x 5 s, 8 distinct utterances —
+    cut into 2, 3 and 4 windows on as many HIP streams, block i on window k + 1 beside block i + 1 on window k.  The windows
+    start on the attention kernel's tile boundaries and the inner inter-LSTM boundaries carry the cell state in the kernel's
+    internal form, so the output must equal the whole-clip forward BIT FOR BIT (repeated: the cross-stream dependences are
+    two events per block and window, a missing one shows up as a run-to-run difference); then a ragged batch with non-zero state
+    in and the next state out (B = 14: windows of 320 + 305 frames), against the whole-clip path."""
+    cfg, sd = oracle_cfg_sd
+    net = nets["f16x3"]
+    d = synth.batch(list(range(8)), 80000)
+    mix = d["mixture"].repeat(4, 1, 1).contiguous().to(DEV)
+    emb = d["embedding_gt"].repeat(4, 1, 1).contiguous().to(DEV)
+    try:
+        with torch.no_grad():
+            net.time_chunks = 1
+            y1 = net(mix, emb).clone()
+            for K in (2, 3, 4):
+                net.time_chunks = K
+                assert net._n_time_chunks(32, 625, 1) == K
+                for rep in range(3):
+                    yk = net(mix, emb)
+                    assert torch.equal(yk, y1), (K, rep, float((yk - y1).abs().max()))
+            assert not net.range_status(DEV)
+            # non-zero state in, next state out; ragged tiles (B = 14: 14 * 97 sequences, 14 * Tc frames are no multiples of 16)
+            B, T = 14, 625
+            d = synth.batch(list(range(40, 40 + B)), 128 * T + 64)
+            st = O.random_state(cfg, B, 5)
+            to_dev = lambda s_: {k: ({kk: {k3: v3.to(DEV) for k3, v3 in vv.items()} for kk, vv in v.items()}
+                                     if isinstance(v, dict) else v.to(DEV)) for k, v in s_.items()}
+            net.time_chunks = 1
+            ya, sa = net.predict(d["mixture"].to(DEV), d["embedding_gt"][:, 0].to(DEV), to_dev(O.clone_state(st)), pad=False)
+            net.time_chunks = 2
+            assert net._n_time_chunks(B, T, 1) == 2 and net._window_bounds(B, T, 2) == [0, 320, 625]
+            yb, sb = net.predict(d["mixture"].to(DEV), d["embedding_gt"][:, 0].to(DEV), to_dev(O.clone_state(st)), pad=False)
+            assert torch.equal(ya, yb)
+            fa, fb = O.flat_state(sa), O.flat_state(sb)
+            for k in fa:
+                assert torch.equal(fa[k], fb[k]), k
+            # and a whole-clip forward from the zero state right after a stateful chunked one (history rows re-zeroed per block)
+            net.time_chunks = 1
+            yz1 = net(mix[:14], emb[:14]).clone()
+            net.time_chunks = 2
+            assert torch.equal(net(mix[:14], emb[:14]), yz1)
+    finally:
+        net.time_chunks = 1
