@@ -35,7 +35,8 @@ def timeline(db, out, marker):
         a, b = marks[-2], marks[-1]
         with open(out, "w") as f:
             f.write(f"# dispatches {a}..{b - 1} of {t}: one step, from `{marker}` to the next one (us)\n")
-            f.write(f"# {'kernel':<60} {'dur_us':>9} {'gap_us':>8}\n")
+            f.write(f"# {'kernel':<60} {'start_us':>9} {'dur_us':>9} {'gap_us':>8}   (start: from the step's first dispatch; dispatches of "
+                    f"concurrent streams overlap: gap < 0)\n")
             tot = gaps = small = 0.0
             for i in range(a, b):
                 n, st, en = rows[i]
@@ -45,7 +46,7 @@ def timeline(db, out, marker):
                 gaps += max(gap, 0.0)
                 if d < 100.0:
                     small += d
-                f.write(f"{short(n)[:60]:<62} {d:9.1f} {gap:8.1f}\n")
+                f.write(f"{short(n)[:60]:<62} {(st - rows[a][1]) / 1e3:9.1f} {d:9.1f} {gap:8.1f}\n")
             f.write(f"# span {(rows[b][1] - rows[a][1]) / 1e3:.1f} us = kernels {tot:.1f} + gaps {gaps:.1f}; "
                     f"dispatches shorter than 100 us: {small:.1f} us\n")
         print("wrote", out, b - a, "dispatches")
