@@ -115,7 +115,15 @@ __global__ void __launch_bounds__(256, 2) k_intra_xp(const float* __restrict__ x
         const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID[3:0] = wave slot
         if (hw_id & 1) __builtin_amdgcn_s_setprio(2);
     }
+#if defined(LH_PROBE_INTRA1)       // timing probe build only (WRONG results: the reverse tiles race the forward ones): both directions of
+    const int nt1 = (nseq + NS - 1) / NS;      // lh_intra_block in ONE launch, forward tiles first (what would it buy?)
+    dir = (int)blockIdx.x >= nt1;
+    accumulate = dir;
+    wlin_pk += (long)dir * 4 * 2 * 64 * 16;
+    const int s0 = ((int)blockIdx.x - dir * nt1) * NS;
+#else
     const int s0 = blockIdx.x * NS;
+#endif
     const int g4 = lane >> 4, l15 = lane & 15;
     const int q = tid & 15;
     const int unit = wave * 16 + l15;
@@ -817,6 +825,12 @@ int xp_set(int key, int v) {
 
 int launch_intra_xp(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin, float* out,
                     int nseq, int nstep, int sdiv, int so, int si, int ps, int dir, int accumulate, hipStream_t st) {
+#if defined(LH_PROBE_INTRA1)
+    if (dir == 1) return LH_OK;               // the forward call launched both directions (wlin_pk: its own pointer, + 0)
+    hipLaunchKernelGGL(k_intra_xp, dim3(2 * ((nseq + 15) / 16)), dim3(256), g_xp_lds_pad, st, x, (const _Float16*)w_pk, b_sum,
+                       (const _Float16*)wlin_pk, blin, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate, g_xp_prio);
+    return check_launch();
+#endif
     hipLaunchKernelGGL(k_intra_xp, dim3((nseq + 15) / 16), dim3(256), g_xp_lds_pad, st, x, (const _Float16*)w_pk, b_sum,
                        (const _Float16*)wlin_pk, blin, out, nseq, nstep, sdiv, so, si, ps, dir, accumulate, g_xp_prio);
     return check_launch();
