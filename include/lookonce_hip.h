@@ -295,6 +295,8 @@ int lh_proj_ln_res_win(const float* merged, const void* w_pk, const float* bias,
                        lh_stream_t stream);
 
 /* ---- plain-fp32 reference kernels of the frame stages (gemm_mode "f32all"; lh_ref32.hip) ----------------------------------
+ * NON-PRODUCT: test / diagnosis kernels that ship in the library so that a host can bisect a disagreement with a real
+ * checkpoint without a second build.  Never benchmark them, never route a product path through them.
  * The product frame kernels above are split-precision (fp16 hi + lo, ~22 bits) in EVERY arithmetic mode; with these and the
  * exact fp32-MFMA recurrences (lh_ln_lstm_intra / _inter in LH_GEMM_F32) a forward exists whose every contraction is an
  * fp32 fmaf chain like the reference's (tfgridnet_causal.py:188-283): the A/B that separates split-precision error from a
