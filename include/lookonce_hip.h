@@ -284,6 +284,11 @@ int lh_intra_block_win(const float* x, const void* w_pk, const float* b_sum, con
 int lh_inter_block_win(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                        const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T, int t0, int Tc,
                        int carry, lh_stream_t stream);
+/* the batch <= 5 form of the inter stage (lh_inter_matvec) on a window; `carry` as above.  Windows that start on multiples of
+ * its 64-step chunk reproduce the whole-clip launch bit for bit. */
+int lh_inter_matvec_win(const float* x, const void* wih_pk, const float* b_sum, const float* whh, const void* wlin_pk,
+                        const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,
+                        int t0, int Tc, int carry, lh_stream_t stream);
 int lh_qkv_proj_ln_win(const float* y, const void* w_pk, const float* bias, const float* slopes, const float* lnq_w,
                        const float* lnq_b, const float* lnk_w, const float* lnk_b, const float* lnv_w,
                        const float* lnv_b, void* q, void* kx, void* vx, const int* ring_pos, int B, int T, int t0, int Tc,

@@ -224,7 +224,11 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
                                                         const _Float16* __restrict__ wlin_pk, const float* __restrict__ blin,
                                                         const float* __restrict__ h0, const float* __restrict__ c0,
                                                         float* __restrict__ hN, float* __restrict__ cN,
-                                                        float* __restrict__ out, int T) {
+                                                        float* __restrict__ out, int T, int Tfull, int tw0, int cflags) {
+    // time window (lh_inter_matvec_win): steps 0 .. T-1 of the launch are frames tw0 .. tw0+T-1 of buffers laid out for Tfull
+    // frames; cflags bit 0 = c0 holds the kernel's scaled cell state (QS_K2 c, written by the previous window with bit 1),
+    // bit 1 = cN is written that way (like k_inter_xp: the windows then reproduce the whole-clip launch bit for bit when
+    // they start on multiples of the 64-step chunk)
     __shared__ __attribute__((aligned(16))) _Float16 xhi[IM_A];          // LN(x) of the chunk's steps
     __shared__ __attribute__((aligned(16))) _Float16 xlo[IM_A];
     __shared__ __attribute__((aligned(16))) _Float16 hhi[IM_A];          // h_t of the chunk's steps
@@ -234,15 +238,15 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float hs[2][H];              // h_{t-1} / h_t
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
     const int seq = blockIdx.x, b = seq / NF, f = seq % NF;              // state row b*97 + f
-    const float* xs = x + ((long)b * T * NF + f) * C;                    // step t -> + t * 97 * 64
-    float* os = out + ((long)b * T * NF + f) * C;
+    const float* xs = x + (((long)b * Tfull + tw0) * NF + f) * C;        // step t -> + t * 97 * 64
+    float* os = out + (((long)b * Tfull + tw0) * NF + f) * C;
     const long tstride = (long)NF * C;
 
     const int unit = (tid & (IS_NR - 1)) >> 2, qs = tid & 3;            // hidden unit, k slice (quad_step): threads < 256
     f32x2 wr[4][8];
     quad_load_w(whh, unit, qs, wr);
     const bool cell_lane = qs == 1 && tid < IS_NR;
-    float c = cell_lane ? QS_K2 * c0[(long)seq * H + unit] : 0.f;       // carried times QS_K2
+    float c = cell_lane ? ((cflags & 1) ? 1.0f : QS_K2) * c0[(long)seq * H + unit] : 0.f;       // carried times QS_K2
     const float gscale = quad_gate_scale(qs);
     if (tid < H) hs[0][tid] = h0[(long)seq * H + tid];
     int hb = 0;                                                          // hs buffer holding h_{t-1}
@@ -314,7 +318,7 @@ __global__ void __launch_bounds__(IS_NT) k_inter_matvec(const float* __restrict_
         __syncthreads();
     }
     if (tid < H) hN[(long)seq * H + tid] = hs[hb][tid];
-    if (cell_lane) cN[(long)seq * H + unit] = c * (1.0f / QS_K2);
+    if (cell_lane) cN[(long)seq * H + unit] = c * ((cflags & 2) ? 1.0f : 1.0f / QS_K2);
 }
 
 }  // namespace lh
@@ -328,14 +332,20 @@ extern "C" int lh_intra_stream(const float* x, const void* wih_pk, const float* 
     return check_launch();
 }
 
-extern "C" int lh_inter_matvec(const float* x, const void* wih_pk, const float* b_sum, const float* whh, const void* wlin_pk,
-                               const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out,
-                               int B, int T, lh_stream_t stream) {
+extern "C" int lh_inter_matvec_win(const float* x, const void* wih_pk, const float* b_sum, const float* whh, const void* wlin_pk,
+                                   const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out,
+                                   int B, int T, int t0, int Tc, int carry, lh_stream_t stream) {
     using namespace lh;
     if (!x || !wih_pk || !b_sum || !whh || !wlin_pk || !blin || !h0 || !c0 || !hN || !cN || !out || B <= 0 || T <= 0)
         return LH_ERR_ARG;
-    if (h0 == hN || c0 == cN || x == out) return LH_ERR_ARG;
+    if (h0 == hN || c0 == cN || x == out || t0 < 0 || Tc <= 0 || t0 + Tc > T || (carry & ~3)) return LH_ERR_ARG;
     hipLaunchKernelGGL(k_inter_matvec, dim3(B * NF), dim3(IS_NT), 0, (hipStream_t)stream, x, (const _Float16*)wih_pk, b_sum,
-                       whh, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, T);
+                       whh, (const _Float16*)wlin_pk, blin, h0, c0, hN, cN, out, Tc, T, t0, carry);
     return check_launch();
+}
+
+extern "C" int lh_inter_matvec(const float* x, const void* wih_pk, const float* b_sum, const float* whh, const void* wlin_pk,
+                               const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out,
+                               int B, int T, lh_stream_t stream) {
+    return lh_inter_matvec_win(x, wih_pk, b_sum, whh, wlin_pk, blin, h0, c0, hN, cN, out, B, T, 0, T, 0, stream);
 }

@@ -215,6 +215,10 @@ class Net(_cabi.HipHost, nn.Module):
         # history = the previous window's rows of the history-extended buffers (one pair per block, so a window that runs
         # ahead cannot overwrite rows a slower one still reads).  1 = off.  LOOKONCE_TIME_CHUNKS overrides.
         self.time_chunks = int(os.environ.get("LOOKONCE_TIME_CHUNKS", "1"))
+        # ... and for ONE utterance (batch 1 offline: the path is latency-bound — 3 x 625 dependent inter-LSTM steps on 97 of
+        # the 256 CUs — so windows of different blocks overlap for free): windows of >= 64 frames on multiples of 64 (the
+        # per-sequence inter kernel's chunk), contiguous in time, the unfused kernels on pointer offsets
+        self.time_chunks_b1 = int(os.environ.get("LOOKONCE_TIME_CHUNKS_B1", "1"))
         self.chunk_min_frames = 64              # >= the 49 frames of attention history: a window then depends on ONE predecessor
         self._chunk_streams: Dict[tuple, list] = {}
         self._pack_key = None
@@ -549,10 +553,15 @@ class Net(_cabi.HipHost, nn.Module):
         """Windows the block loop is cut into: `time_chunks`, when the batch runs the fused batch kernels (the windowed entry
         points are theirs) and every window keeps at least the 49 frames of attention history (a window then only depends on
         its predecessor); 1 otherwise (small batches, streaming, taps, exact-fp32 modes)."""
-        K = int(self.time_chunks)
-        if K <= 1 or mode != 1 or not self.fuse_linear or self._debug_taps is not None:
+        if mode != 1 or not self.fuse_linear or self._debug_taps is not None:
             return 1
         if Bn * self.n_freqs <= self.inter_matvec_max_seqs:
+            # few sequences (lh_inter_matvec): one utterance only — its windows are contiguous in time
+            if Bn != 1 or Bn * T <= self.stream_intra_max_frames or Bn * T >= self.fuse_intra_min_frames:
+                return 1
+            return max(min(int(self.time_chunks_b1), T // max(self.chunk_min_frames, 1)), 1)
+        K = int(self.time_chunks)
+        if K <= 1:
             return 1
         K = min(K, T // max(self.chunk_min_frames, 1))
         while K > 1 and Bn * (T // K) < self.fuse_intra_min_frames // 2:
@@ -566,8 +575,10 @@ class Net(_cabi.HipHost, nn.Module):
         bit-identical to the unchunked one (every other stage is per frame or per sequence)."""
         bh8 = (Bn * self.n_head + 7) // 8 * 8
         align = 40 if bh8 * ((T + 31) // 32) > 512 else 32
+        if Bn * self.n_freqs <= self.inter_matvec_max_seqs:
+            align = 64                                        # lh_inter_matvec's chunk of steps (a multiple of the 32-frame tile)
         cuts = [(k * T) // K for k in range(K + 1)]
-        if T // K >= 2 * align:
+        if T // K >= 2 * align or (align == 64 and T // K >= 64):
             cuts = [0] + [int(round(k * T / K / align)) * align for k in range(1, K)] + [T]
         return cuts
 
@@ -588,6 +599,7 @@ class Net(_cabi.HipHost, nn.Module):
         c32 = lambda t: t.contiguous().float()
         xa, xb, xc = ws["xa"], ws["xb"], ws["xc"]
         lanes = self._lanes(dev, K)
+        small = Bn * F_ <= self.inter_matvec_max_seqs          # one utterance: unfused intra pair + lh_inter_matvec (whole-clip rule)
         if "kxb" not in ws:                                   # one history-extended K / V pair per block
             z16 = lambda *s_: torch.zeros(*s_, device=dev, dtype=torch.float16)
             ws["kxb"] = [ws["kx"]] + [z16(*ws["kx"].shape) for _ in range(self.n_blocks - 1)]
@@ -621,15 +633,30 @@ class Net(_cabi.HipHost, nn.Module):
             ev_r = ev_q = None                                # the previous window's (h, c) / K, V rows of THIS block
             for k in range(K):
                 t0, Tc = bounds[k], bounds[k + 1] - bounds[k]
+                carry = (1 if k > 0 else 0) | (2 if k + 1 < K else 0)     # inner boundaries: internal cell-state form
                 with lanes.on(k):
                     st = self._stream(dev)
-                    lib.call("lh_intra_block_win", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
-                             P(bp["intra_lin_b"]), P(xb), Bn, T, t0, Tc, st)
+                    if small:
+                        # one utterance: the window's frames are contiguous — the whole-clip path's unfused intra pair on offsets
+                        o = t0 * F_ * self.emb_dim * 4
+                        oh = t0 * F_ * 2 * self.hidden * 4
+                        lib.call("lh_ln_lstm_intra", P(xa) + o, P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra_w16"]),
+                                 P(bp["intra_b16"]), P(ws["hbuf"]) + oh, Tc, 1, st)
+                        lib.call("lh_linear_res", P(ws["hbuf"]) + oh, P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa) + o,
+                                 P(xb) + o, Tc * F_, 2 * self.hidden, st)
+                    else:
+                        lib.call("lh_intra_block_win", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
+                                 P(bp["intra_lin_b"]), P(xb), Bn, T, t0, Tc, st)
                     if k > 0:
                         lanes.wait(k, ev_r)
-                    lib.call("lh_inter_block_win", P(xb), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
-                             P(bp["inter_lin_b"]), P(hs[i][k]), P(cs[i][k]), P(hs[i][k + 1]), P(cs[i][k + 1]), P(xc), Bn, T, t0,
-                             Tc, (1 if k > 0 else 0) | (2 if k + 1 < K else 0), st)  # inner boundaries: internal cell-state form
+                    if small:
+                        lib.call("lh_inter_matvec_win", P(xb), P(bp["inter_s_wih"]), P(bp["inter_s_b"]), P(bp["inter_s_whh"]),
+                                 P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(hs[i][k]), P(cs[i][k]), P(hs[i][k + 1]),
+                                 P(cs[i][k + 1]), P(xc), Bn, T, t0, Tc, carry, st)
+                    else:
+                        lib.call("lh_inter_block_win", P(xb), P(bp["inter_w8"]), P(bp["inter_b16"]), P(bp["inter_lin_wu"]),
+                                 P(bp["inter_lin_b"]), P(hs[i][k]), P(cs[i][k]), P(hs[i][k + 1]), P(cs[i][k + 1]), P(xc), Bn, T,
+                                 t0, Tc, carry, st)
                     if k + 1 < K:
                         ev_r = lanes.signal(k)
                     lib.call("lh_qkv_proj_ln_win", P(xc), P(bp["qkv_w"]), P(bp["qkv_b"]), P(bp["qkv_slopes"]), P(bp["lnq_w"]),

@@ -146,6 +146,33 @@ def test_time_windows_equal_the_whole_clip(emu_net, oracle_cfg_sd):
     assert (yz - yzo).abs().max() < TOL
 
 
+def test_time_windows_of_one_utterance(emu_net, oracle_cfg_sd):
+    """`Net.time_chunks_b1`: ONE utterance (the latency-bound batch-1 path: unfused intra pair + the per-sequence inter kernel,
+    here through `lh_inter_matvec_win`), T = 34 frames cut into windows of 17, non-zero state in, next state out, against the
+    whole-clip launches and the oracle.  Block 0's recurrent stages and Q / K / V rows are bit-identical; the attention of the
+    second window sums in another tile alignment (see the test above)."""
+    cfg, sd = oracle_cfg_sd
+    B, T = 1, 34
+    d = synth.batch([31], 128 * T + 64)
+    st = O.random_state(cfg, B, 17)
+    yo, so = O.predict(cfg, sd, d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    saved = emu_net.stream_intra_max_frames, emu_net.time_chunks_b1, emu_net.chunk_min_frames
+    emu_net.stream_intra_max_frames = 0                     # (34 frames would otherwise take the streaming intra kernel)
+    try:
+        y1, s1 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+        emu_net.time_chunks_b1, emu_net.chunk_min_frames = 2, 2
+        assert emu_net._n_time_chunks(B, T, 1) == 2 and emu_net._window_bounds(B, T, 2) == [0, 17, 34]
+        y2, s2 = emu_net.predict(d["mixture"], d["embedding_gt"][:, 0], O.clone_state(st), pad=False)
+    finally:
+        emu_net.stream_intra_max_frames, emu_net.time_chunks_b1, emu_net.chunk_min_frames = saved
+    assert (y1 - yo).abs().max() < TOL and (y2 - y1).abs().max() < 5e-6 and (y2 - yo).abs().max() < TOL
+    f1, f2, fo = O.flat_state(s1), O.flat_state(s2), O.flat_state(so)
+    for k in fo:
+        assert (f2[k] - f1[k]).abs().max() < 1e-5 and (f2[k] - fo[k]).abs().max() < TOL, k
+    for k in ("h0", "c0", "K_buf", "V_buf"):
+        assert torch.equal(f2["gridnet_bufs.buf0." + k], f1["gridnet_bufs.buf0." + k]), k
+
+
 @pytest.mark.parametrize("tune5", [0, 2, (0, 19)], ids=["k_inter_xp", "k_lstm_lin8p", "k_inter_xp-roles-swapped"])
 def test_fused_inter_kernels(emu_net, oracle_cfg_sd, tune5):
     """k_inter_xp (lh_recur.hip, the default) and the previous k_lstm_lin8p (lh_set_tuning(5, 2)): B=6 (582 sequences = 37 tiles, last one ragged; above
