@@ -123,14 +123,17 @@ class _Lanes:
     stream / event calls of the chunked block loop live here; tests/hipemu/hosts.py substitutes a serial stand-in."""
     serial = False
 
-    def __init__(self, dev, streams):
-        self.dev, self.streams = dev, streams
+    def __init__(self, dev, side_streams):
+        # lane 0 is the CURRENT stream (the chip has four hardware queues per process by default: a fifth stream would share
+        # one and serialise behind it — profiles/r06e: the fourth side stream's first kernel started 300 us late)
+        self.dev = dev
         self.main = torch.cuda.current_stream(dev)
+        self.streams = [self.main] + list(side_streams)
 
     def fork(self):
         ev = torch.cuda.Event()
         ev.record(self.main)
-        for s_ in self.streams:
+        for s_ in self.streams[1:]:
             s_.wait_event(ev)
 
     def on(self, k):
@@ -145,7 +148,7 @@ class _Lanes:
         self.streams[k].wait_event(ev)
 
     def join(self):
-        for s_ in self.streams:
+        for s_ in self.streams[1:]:
             self.main.wait_stream(s_)
 
 
@@ -218,7 +221,10 @@ class Net(_cabi.HipHost, nn.Module):
         # ... and for ONE utterance (batch 1 offline: the path is latency-bound — 3 x 625 dependent inter-LSTM steps on 97 of
         # the 256 CUs — so windows of different blocks overlap for free): windows of >= 64 frames on multiples of 64 (the
         # per-sequence inter kernel's chunk), contiguous in time, the unfused kernels on pointer offsets
-        self.time_chunks_b1 = int(os.environ.get("LOOKONCE_TIME_CHUNKS_B1", "1"))
+        # Measured (profiles/r06e_time_chunks_b1.txt): 2 windows 1.31 -> 1.11 ms per 5 s clip (-15 %, bit-identical); more windows
+        # lose again (every hand-over between windows is a cross-stream event, ~10-20 us on this runtime, and a fifth stream shares
+        # a hardware queue), also when the whole forward is replayed as one hipGraph.  Default 2.
+        self.time_chunks_b1 = int(os.environ.get("LOOKONCE_TIME_CHUNKS_B1", "2"))
         self.chunk_min_frames = 64              # >= the 49 frames of attention history: a window then depends on ONE predecessor
         self._chunk_streams: Dict[tuple, list] = {}
         self._pack_key = None
@@ -585,7 +591,7 @@ class Net(_cabi.HipHost, nn.Module):
     def _lanes(self, dev, K) -> _Lanes:
         key = (str(dev), K)
         if key not in self._chunk_streams:
-            self._chunk_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(K)]
+            self._chunk_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
         if self.chunk_min_frames < self.local_atten_len - 1:
             raise ValueError("chunk_min_frames must cover the attention history (49 frames) on concurrent streams")
         return _Lanes(dev, self._chunk_streams[key])
