@@ -1100,6 +1100,10 @@ def main():
             for k_ in ("mfma_busy", "valu_busy"):
                 if k_ in tj_dom:
                     roof[k_] = tj_dom[k_]
+            if "ratio_to_survey_8d_per_call" in tj_dom:     # the contract's byte count for the stage (2 A), next to the kernel's own
+                roof["traffic_ratio_to_survey_8d_stage_bytes"] = tj_dom["ratio_to_survey_8d_per_call"]
+                roof["traffic_note"] = ("traffic = counter bytes per launch; two launches per call move 5 A by construction (forward: "
+                                        "read x, write out; reverse: read x, read + rewrite out) against SURVEY §8(d)'s 2 A for the stage")
             if "rocprof_avg_launch_us" in tj_dom:
                 # the committed rocprofv3 --kernel-trace --stats summary times the same launch with every dispatch separated by
                 # the tracer (and at its own clocks): ~10 % longer than the HIP-event figure of back-to-back launches above.

@@ -89,6 +89,12 @@ def main(fetch_csv, write_csv, batch, out_json, sq_csv=None, sq2_csv=None, stats
             "algorithmic_bytes_per_launch": alg,
         }
         kernels[call]["ratio_to_algorithmic"] = kernels[call]["hbm_bytes_per_launch"] / alg
+        if call == "lh_intra_block":
+            # this kernel's "algorithmic" figure is what ITS two-launch structure must move (forward: read x,
+            # write out; reverse: read x, read + rewrite out = 5 A per call); SURVEY.md §8(d) budgets the intra STAGE at 2 A
+            # (read A, write A).  Both ratios are stated; 2 A is not reachable on this chip.
+            kernels[call]["survey_8d_bytes_per_call"] = 2.0 * A
+            kernels[call]["ratio_to_survey_8d_per_call"] = 2 * kernels[call]["hbm_bytes_per_launch"] / (2.0 * A)
         if f[0][0][0] in tm:        # the same launch as rocprofv3's tracer times it (every dispatch separated: longer than back to back)
             kernels[call]["rocprof_avg_launch_us"] = tm[f[0][0][0]][1]
         c = sq.get(f[0][0])
