@@ -462,16 +462,10 @@ class Net(_cabi.HipHost, nn.Module):
             lib_, lib = lib, _Timed
 
             conv_in = c32(state["conv_buf"]); conv_out = new(conv_in)
-            # the speaker gain (two dependent launches on B rows: ~35 us of latency, nothing to do with the batch) runs on a second
-            # stream beside the front end instead of in front of it; block 0's projection is its first reader
-            side = self._lanes(dev, 2)
-            side.fork()
-            with side.on(1):
-                lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]),
-                         P(pk["emb_ln_b"]), P(ws["gain_raw"]), P(ws["gain"]), Bn, self._stream(dev))
             lib.call("lh_stft_conv_in", P(x), P(conv_in), P(conv_out), P(pk["wfb_t"]), P(pk["conv_w"]),
                      P(pk["conv_b"]), P(xa), Bn, T, ns, st)
-            side.join()
+            lib.call("lh_embed_proj_ln", P(embed), P(pk["emb_w"]), P(pk["emb_b"]), P(pk["emb_ln_w"]),
+                     P(pk["emb_ln_b"]), P(ws["gain_raw"]), P(ws["gain"]), Bn, st)
             if taps is not None:
                 taps["Z0"], taps["G"] = xa.clone(), ws["gain"].clone()
 
