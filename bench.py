@@ -687,35 +687,6 @@ def secondary_measurements(net, dev, mix8, emb8):
             net.gemm_mode = "f16x3"
             net._ws.clear()
             torch.cuda.empty_cache()
-        # time-axis windows of ONE batch on K streams (Net.time_chunks; VERDICT r5 item 4): same-process A/B over K, each
-        # forward held bit for bit against the whole-clip one
-        try:
-            B = 32
-            mix = mix8.repeat(4, 1, 1).contiguous()
-            emb = emb8.repeat(4, 1, 1).contiguous()
-            keep = net.time_chunks
-            tab = {}
-            net.time_chunks = 1
-            y1 = net(mix, emb).clone()
-            for K in (1, 2, 3, 4, 1):
-                net.time_chunks = K
-                same = bool(torch.equal(net(mix, emb), y1))
-                ms = _time_forward(lambda: net(mix, emb), 10, 3)
-                tab.setdefault(str(K), []).append(ms)
-                log(f"offline B=32 time_chunks={K}: {ms:.3f} ms, bit-identical to the whole clip: {same}")
-                tab[f"{K}_bit_identical"] = same
-            net.time_chunks = keep
-            out["offline_b32_time_chunks"] = {"ms_per_step_by_chunks": {k: v for k, v in tab.items() if not k.endswith("identical")},
-                                              "bit_identical_to_whole_clip": {k[:-14]: v for k, v in tab.items() if k.endswith("identical")},
-                                              "default_time_chunks": keep,
-                                              "workload": "the headline batch (ONE batch in flight) with the time axis cut into K "
-                                                          "windows on K HIP streams; forward only (no metric sums), 10 steps each, "
-                                                          "K = 1 measured first and last"}
-            del y1, mix, emb
-        except Exception as e:
-            out["offline_b32_time_chunks"] = {"error": repr(e)[:200]}
-        net._ws.clear()
-        torch.cuda.empty_cache()
         # two batches in flight (context for DESIGN.md §11, NOT the headline): two Net replicas with the same weights on two HIP
         # streams, steps alternating — what the CUs the inter LSTM leaves idle (194 of 256 busy) are worth to a caller that has
         # the next batch ready.  ms = wall / batches: an inverse throughput, not a latency.
@@ -728,7 +699,9 @@ def secondary_measurements(net, dev, mix8, emb8):
             net2 = Net(**config.TSH_PARAMS).eval()
             net2.load_state_dict(net.state_dict(), strict=True)
             net2 = net2.to(dev)
-            nets, streams = [net, net2], [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            # (the Net's own pool of side streams — the ones `time_chunks_b1` uses — instead of two more: past four streams per
+            # process the hardware queues are shared and the legs below would depend on which stream landed where)
+            nets, streams = [net, net2], net._lanes(dev, 3).streams[1:3]
             cur = torch.cuda.current_stream(dev)
 
             def in_flight(n):
@@ -888,6 +861,36 @@ def secondary_measurements(net, dev, mix8, emb8):
         out["stream_table"] = {"by_batch": table,
                                "note": "B streams advanced together, one graph replay per 8 ms chunk incl. the host sync a real-time "
                                        "consumer needs; realtime_streams = B x (4 ms / p99): time-multiplexed groups of B at RTF 0.5"}
+        # time-axis windows of ONE batch on K streams (Net.time_chunks; VERDICT r5 item 4): same-process A/B over K, each
+        # forward held bit for bit against the whole-clip one.  LAST leg on purpose: its window streams stay in the process, and
+        # more streams than hardware queues (four) change how the legs above would overlap their own streams
+        try:
+            B = 32
+            mix = mix8.repeat(4, 1, 1).contiguous()
+            emb = emb8.repeat(4, 1, 1).contiguous()
+            keep = net.time_chunks
+            tab = {}
+            net.time_chunks = 1
+            y1 = net(mix, emb).clone()
+            for K in (1, 2, 3, 4, 1):
+                net.time_chunks = K
+                same = bool(torch.equal(net(mix, emb), y1))
+                ms = _time_forward(lambda: net(mix, emb), 10, 3)
+                tab.setdefault(str(K), []).append(ms)
+                log(f"offline B=32 time_chunks={K}: {ms:.3f} ms, bit-identical to the whole clip: {same}")
+                tab[f"{K}_bit_identical"] = same
+            net.time_chunks = keep
+            out["offline_b32_time_chunks"] = {"ms_per_step_by_chunks": {k: v for k, v in tab.items() if not k.endswith("identical")},
+                                              "bit_identical_to_whole_clip": {k[:-14]: v for k, v in tab.items() if k.endswith("identical")},
+                                              "default_time_chunks": keep,
+                                              "workload": "the headline batch (ONE batch in flight) with the time axis cut into K "
+                                                          "windows on K HIP streams; forward only (no metric sums), 10 steps each, "
+                                                          "K = 1 measured first and last"}
+            del y1, mix, emb
+        except Exception as e:
+            out["offline_b32_time_chunks"] = {"error": repr(e)[:200]}
+        net._ws.clear()
+        torch.cuda.empty_cache()
     return out
 
 

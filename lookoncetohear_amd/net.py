@@ -226,7 +226,7 @@ class Net(_cabi.HipHost, nn.Module):
         # a hardware queue), also when the whole forward is replayed as one hipGraph.  Default 2.
         self.time_chunks_b1 = int(os.environ.get("LOOKONCE_TIME_CHUNKS_B1", "2"))
         self.chunk_min_frames = 64              # >= the 49 frames of attention history: a window then depends on ONE predecessor
-        self._chunk_streams: Dict[tuple, list] = {}
+        self._chunk_streams: Dict[str, list] = {}
         self._pack_key = None
         self._packed = None
         self._ws: Dict[tuple, dict] = {}
@@ -589,12 +589,15 @@ class Net(_cabi.HipHost, nn.Module):
         return cuts
 
     def _lanes(self, dev, K) -> _Lanes:
-        key = (str(dev), K)
-        if key not in self._chunk_streams:
-            self._chunk_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
+        # ONE pool of side streams per device, grown on demand and shared by every window count: the process has four hardware
+        # queues, and every further stream shares one with somebody (a bench run that had left six window streams behind slowed
+        # the EMBEDDER's two-stream forward from 59.7 to 68.4 ms: its side stream had landed on a busy queue)
+        pool = self._chunk_streams.setdefault(str(dev), [])
+        while len(pool) < K - 1:
+            pool.append(torch.cuda.Stream(device=dev))
         if self.chunk_min_frames < self.local_atten_len - 1:
             raise ValueError("chunk_min_frames must cover the attention history (49 frames) on concurrent streams")
-        return _Lanes(dev, self._chunk_streams[key])
+        return _Lanes(dev, pool[:K - 1])
 
     def _blocks_chunked(self, lib, pk, ws, state, Bn, T, dev, from_zero, want_state, K):
         """The three GridNet blocks (tfgridnet_causal.py:489-590) with the time axis cut into K windows, window k on stream k:
