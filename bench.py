@@ -699,7 +699,7 @@ def secondary_measurements(net, dev, mix8, emb8):
             net2 = Net(**config.TSH_PARAMS).eval()
             net2.load_state_dict(net.state_dict(), strict=True)
             net2 = net2.to(dev)
-            # (the Net's own pool of side streams — the ones `time_chunks_b1` uses — instead of two more: past four streams per
+            # (the Net's own pool of side streams — the ones `time_chunks_small` uses — instead of two more: past four streams per
             # process the hardware queues are shared and the legs below would depend on which stream landed where)
             nets, streams = [net, net2], net._lanes(dev, 3).streams[1:3]
             cur = torch.cuda.current_stream(dev)

@@ -284,6 +284,12 @@ int lh_intra_block_win(const float* x, const void* w_pk, const float* b_sum, con
 int lh_inter_block_win(const float* x, const void* w_pk, const float* b_sum, const void* wlin_pk, const float* blin,
                        const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T, int t0, int Tc,
                        int carry, lh_stream_t stream);
+/* the unfused intra pair of small batches on a window (split-precision mode): lh_ln_lstm_intra + lh_linear_res on frames (b, t0 + j);
+ * h_out / h [B*T*97][128] in the (b, t, f) row order of x */
+int lh_ln_lstm_intra_win(const float* x, const float* ln_w, const float* ln_b, const void* w_pk, const float* b_sum, float* h_out,
+                         int B, int T, int t0, int Tc, lh_stream_t stream);
+int lh_linear_res_win(const float* h, const void* w_pk, const float* bias, const float* res, float* out, int B, int T, int t0,
+                      int Tc, int K, lh_stream_t stream);
 /* the batch <= 5 form of the inter stage (lh_inter_matvec) on a window; `carry` as above.  Windows that start on multiples of
  * its 64-step chunk reproduce the whole-clip launch bit for bit. */
 int lh_inter_matvec_win(const float* x, const void* wih_pk, const float* b_sum, const float* whh, const void* wlin_pk,

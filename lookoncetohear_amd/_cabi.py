@@ -38,6 +38,8 @@ SIGNATURES = {
     # time windows (ABI 14): the five block stages on frames [t0, t0 + Tc) of [B][T][97][64] buffers (net.py `time_chunks`)
     "lh_intra_block_win": [_P] * 6 + [_I, _I, _I, _I, _P],
     "lh_inter_block_win": [_P] * 10 + [_I, _I, _I, _I, _I, _P],
+    "lh_ln_lstm_intra_win": [_P] * 6 + [_I, _I, _I, _I, _P],
+    "lh_linear_res_win": [_P] * 5 + [_I, _I, _I, _I, _I, _P],
     "lh_inter_matvec_win": [_P] * 11 + [_I, _I, _I, _I, _I, _P],
     "lh_qkv_proj_ln_win": [_P] * 14 + [_I, _I, _I, _I, _P],
     "lh_local_attn_win": [_P] * 4 + [_I, _I, _I, _I, _P],

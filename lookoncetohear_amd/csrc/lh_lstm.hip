@@ -1107,6 +1107,17 @@ extern "C" int lh_ln_lstm_intra(const float* x, const float* ln_w, const float* 
                           0, 1, 2 * H, (hipStream_t)stream);
 }
 
+// time window of the unfused intra pass (batches below the fused kernels' size): frames (b, t0 + j), one 16-sequence tile
+// shape (a window of a small batch is a single round of workgroups anyway)
+extern "C" int lh_ln_lstm_intra_win(const float* x, const float* ln_w, const float* ln_b, const void* w_pk, const float* b_sum,
+                                    float* h_out, int B, int T, int t0, int Tc, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !ln_w || !ln_b || !w_pk || !b_sum || !h_out || B <= 0 || T <= 0 || t0 < 0 || Tc <= 0 || t0 + Tc > T) return LH_ERR_ARG;
+    const long off = (long)t0 * NF;
+    return launch_lstm_h3<1>(x + off * C, ln_w, ln_b, w_pk, b_sum, nullptr, nullptr, nullptr, nullptr, h_out + off * 2 * H, B * Tc,
+                             NF, 2, Tc, T * NF, NF, 1, 2 * H, (hipStream_t)stream);
+}
+
 extern "C" int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const void* w_pk,
                                 const float* b_sum, const float* h0, const float* c0, float* hN, float* cN,
                                 float* h_out, int B, int T, int mode, lh_stream_t stream) {

@@ -25,7 +25,10 @@ namespace lh {
 template <int K>
 __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h, const _Float16* __restrict__ w_pk,
                                                     const float* __restrict__ bias, const float* __restrict__ res,
-                                                    float* __restrict__ out, int rows) {
+                                                    float* __restrict__ out, int rows, int seg, long segstride) {
+    // rows come in segments of `seg` consecutive rows, segment g starting at row g * segstride (time windows, lh_linear_res_win:
+    // seg = Tc * 97 rows of one utterance, segstride = T * 97); the plain call is ONE segment (seg = rows)
+    auto grow = [&](long r) -> long { return (r / seg) * segstride + r % seg; };
     constexpr int KS = K / 32, RP = 64, CP = C + 4;
     __shared__ __attribute__((aligned(16))) _Float16 ahi[KS * 4 * RP * 8];
     __shared__ __attribute__((aligned(16))) _Float16 alo[KS * 4 * RP * 8];
@@ -44,7 +47,7 @@ __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h,
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {                // all global loads of the tile in flight
             const int e = tid + 256 * i;
-            const long r = min(r0 + e / (K / 4), (long)rows - 1);
+            const long r = grow(min(r0 + e / (K / 4), (long)rows - 1));
             stg[i] = *reinterpret_cast<const float4*>(&h[r * K + (e % (K / 4)) * 4]);
         }
         // residual rows: issue the loads now, they land while the MFMAs run
@@ -52,7 +55,7 @@ __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
-            const long r = min(r0 + (e >> 4), (long)rows - 1);
+            const long r = grow(min(r0 + (e >> 4), (long)rows - 1));
             rv[i] = *reinterpret_cast<const float4*>(&res[r * C + (e & 15) * 4]);
         }
 #pragma unroll
@@ -74,7 +77,7 @@ __global__ void __launch_bounds__(256) k_linear_res(const float* __restrict__ h,
             const long r = r0 + rr;
             if (r < rows) {
                 const float4 cv = *reinterpret_cast<const float4*>(&cs[rr * CP + qq * 4]);
-                *reinterpret_cast<float4*>(&out[r * C + qq * 4]) =
+                *reinterpret_cast<float4*>(&out[grow(r) * C + qq * 4]) =
                     make_float4(cv.x + rv[i].x, cv.y + rv[i].y, cv.z + rv[i].z, cv.w + rv[i].w);
             }
         }
@@ -449,21 +452,36 @@ __global__ void __launch_bounds__(256, 2) k_proj_ln_res(const float* __restrict_
 
 }  // namespace lh
 
-extern "C" int lh_linear_res(const float* h, const void* w_pk, const float* bias, const float* res, float* out,
-                             int rows, int K, lh_stream_t stream) {
+static int launch_linear_res(const float* h, const void* w_pk, const float* bias, const float* res, float* out, int rows, int K,
+                             int seg, long segstride, hipStream_t st) {
     using namespace lh;
-    if (!h || !w_pk || !bias || !res || !out || rows <= 0) return LH_ERR_ARG;
     const int ntiles = (rows + 63) / 64;
     const int grid = ntiles < 768 ? ntiles : 768;
     if (K == 128)
-        hipLaunchKernelGGL((k_linear_res<128>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, (const _Float16*)w_pk,
-                           bias, res, out, rows);
+        hipLaunchKernelGGL((k_linear_res<128>), dim3(grid), dim3(256), 0, st, h, (const _Float16*)w_pk, bias, res, out, rows, seg,
+                           segstride);
     else if (K == 64)
-        hipLaunchKernelGGL((k_linear_res<64>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h, (const _Float16*)w_pk,
-                           bias, res, out, rows);
+        hipLaunchKernelGGL((k_linear_res<64>), dim3(grid), dim3(256), 0, st, h, (const _Float16*)w_pk, bias, res, out, rows, seg,
+                           segstride);
     else
         return LH_ERR_UNSUPPORTED;
     return check_launch();
+}
+
+extern "C" int lh_linear_res(const float* h, const void* w_pk, const float* bias, const float* res, float* out,
+                             int rows, int K, lh_stream_t stream) {
+    if (!h || !w_pk || !bias || !res || !out || rows <= 0) return LH_ERR_ARG;
+    return launch_linear_res(h, w_pk, bias, res, out, rows, K, rows, 0L, (hipStream_t)stream);
+}
+
+// time window: rows (b, t0 + j, f) of [B][T][97][..] buffers — h [B*T*97][K], res / out [B*T*97][64]
+extern "C" int lh_linear_res_win(const float* h, const void* w_pk, const float* bias, const float* res, float* out, int B, int T,
+                                 int t0, int Tc, int K, lh_stream_t stream) {
+    using namespace lh;
+    if (!h || !w_pk || !bias || !res || !out || B <= 0 || T <= 0 || t0 < 0 || Tc <= 0 || t0 + Tc > T) return LH_ERR_ARG;
+    const long off = (long)t0 * NF;
+    return launch_linear_res(h + off * K, w_pk, bias, res + off * C, out + off * C, B * Tc * NF, K, Tc * NF, (long)T * NF,
+                             (hipStream_t)stream);
 }
 
 extern "C" int lh_qkv_proj_ln_win(const float* y, const void* w_pk, const float* bias, const float* slopes,

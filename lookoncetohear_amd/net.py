@@ -212,19 +212,22 @@ class Net(_cabi.HipHost, nn.Module):
         self.inter_matvec_max_seqs = 512        # inter LSTM: per-sequence workgroups up to two rounds of CUs (batch <= 5)
         self.stream_intra_max_frames = 128      # up to here one workgroup per (frame, direction) still finds its own CU
         # time-axis pipelining of the three blocks (round 6; include/lookonce_hip.h "time windows"): every stage is causal in
-        # t, so with time_chunks = K > 1 the frames are cut into K windows, window k on its own HIP stream, and block i on
-        # window k + 1 runs beside block i + 1 on window k — the inter LSTM (a 625-step dependent chain on 194 of the 256 CUs)
-        # overlaps with the other stages of the SAME batch.  State is handed over on the device: (h, c) per window, the K / V
-        # history = the previous window's rows of the history-extended buffers (one pair per block, so a window that runs
-        # ahead cannot overwrite rows a slower one still reads).  1 = off.  LOOKONCE_TIME_CHUNKS overrides.
-        self.time_chunks = int(os.environ.get("LOOKONCE_TIME_CHUNKS", "1"))
-        # ... and for ONE utterance (batch 1 offline: the path is latency-bound — 3 x 625 dependent inter-LSTM steps on 97 of
-        # the 256 CUs — so windows of different blocks overlap for free): windows of >= 64 frames on multiples of 64 (the
-        # per-sequence inter kernel's chunk), contiguous in time, the unfused kernels on pointer offsets
-        # Measured (profiles/r06e_time_chunks_b1.txt): 2 windows 1.31 -> 1.11 ms per 5 s clip (-15 %, bit-identical); more windows
-        # lose again (every hand-over between windows is a cross-stream event, ~10-20 us on this runtime, and a fifth stream shares
-        # a hardware queue), also when the whole forward is replayed as one hipGraph.  Default 2.
-        self.time_chunks_b1 = int(os.environ.get("LOOKONCE_TIME_CHUNKS_B1", "2"))
+        # t, so the frames can be cut into K windows, window k on its own HIP stream, and block i on window k + 1 runs beside
+        # block i + 1 on window k.  State is handed over on the device: (h, c) per window, the K / V history = the previous
+        # window's rows of the history-extended buffers (one pair per block, so a window that runs ahead cannot overwrite rows a
+        # slower one still reads); the output is bit-identical to the whole-clip forward.  What it buys depends on how much of
+        # the chip one launch fills (profiles/r06b, r06e, r06h): the inter LSTM is a 625-step dependent chain on ceil(97 B / 16)
+        # CUs, and every small-batch launch is latency-bound —
+        #   time_chunks        batches on the fused kernels (B T >= 8192 frames: B >= 14 at 5 s).  0 = automatic: 2 windows while
+        #                      the inter launch leaves more than ~30 % of the 256 CUs dark (B <= 29: -19 % at B = 14, -15 % at 16,
+        #                      -11 % at 20, -5 % at 24, -1 % at 28), one from there on (B = 32: +-0, and the per-launch figures of
+        #                      bench.py's roofline object stay those of kernels that run alone); K >= 1 forces K.
+        #   time_chunks_small  smaller batches (unfused intra pair; per-sequence inter kernel up to B = 5, tiled one above),
+        #                      windows on multiples of 64 frames: default 2 (one utterance 1.31 -> 1.11 ms per 5 s clip; more
+        #                      windows lose again: every hand-over is a cross-stream event of 10-20 us on this runtime).
+        # LOOKONCE_TIME_CHUNKS / LOOKONCE_TIME_CHUNKS_SMALL override.
+        self.time_chunks = int(os.environ.get("LOOKONCE_TIME_CHUNKS", "0"))
+        self.time_chunks_small = int(os.environ.get("LOOKONCE_TIME_CHUNKS_SMALL", "2"))
         self.chunk_min_frames = 64              # >= the 49 frames of attention history: a window then depends on ONE predecessor
         self._chunk_streams: Dict[str, list] = {}
         self._pack_key = None
@@ -556,23 +559,25 @@ class Net(_cabi.HipHost, nn.Module):
         return y, (state if want_state else None)
 
     def _n_time_chunks(self, Bn: int, T: int, mode: int) -> int:
-        """Windows the block loop is cut into: `time_chunks`, when the batch runs the fused batch kernels (the windowed entry
-        points are theirs) and every window keeps at least the 49 frames of attention history (a window then only depends on
-        its predecessor); 1 otherwise (small batches, streaming, taps, exact-fp32 modes)."""
+        """Windows the block loop is cut into (see `time_chunks` / `time_chunks_small` in __init__); 1 for streaming-size
+        inputs, stage taps and the exact-fp32 modes.  Every window keeps at least `chunk_min_frames` (>= the 49 frames of
+        attention history: a window then depends on ONE predecessor)."""
         if mode != 1 or not self.fuse_linear or self._debug_taps is not None:
             return 1
-        if Bn * self.n_freqs <= self.inter_matvec_max_seqs:
-            # few sequences (lh_inter_matvec): one utterance only — its windows are contiguous in time
-            if Bn != 1 or Bn * T <= self.stream_intra_max_frames or Bn * T >= self.fuse_intra_min_frames:
-                return 1
-            return max(min(int(self.time_chunks_b1), T // max(self.chunk_min_frames, 1)), 1)
-        K = int(self.time_chunks)
-        if K <= 1:
-            return 1
-        K = min(K, T // max(self.chunk_min_frames, 1))
-        while K > 1 and Bn * (T // K) < self.fuse_intra_min_frames // 2:
-            K -= 1
-        return max(K, 1)
+        if Bn * self.n_freqs <= self.inter_matvec_max_seqs and T < 32:
+            return 1                                             # (the per-sequence inter kernel serves T >= 32, `_separate`)
+        if Bn * T < self.fuse_intra_min_frames:                  # small batches: unfused intra pair
+            if Bn * T <= self.stream_intra_max_frames:
+                return 1                                         # a handful of frames: the streaming intra kernel
+            K = int(self.time_chunks_small)
+        else:
+            K = int(self.time_chunks)
+            if K == 0:                                           # automatic
+                tiles = (Bn * self.n_freqs + 15) // 16           # workgroups (= CUs) of the inter launch
+                K = 2 if tiles < 180 else 1
+            while K > 1 and Bn * (T // K) < self.fuse_intra_min_frames // 2:
+                K -= 1
+        return max(min(K, T // max(self.chunk_min_frames, 1)), 1)
 
     def _window_bounds(self, Bn: int, T: int, K: int) -> list:
         """Window boundaries [0, ..., T]: even cuts, moved to multiples of the attention kernel's query-tile length (40 frames
@@ -608,7 +613,9 @@ class Net(_cabi.HipHost, nn.Module):
         c32 = lambda t: t.contiguous().float()
         xa, xb, xc = ws["xa"], ws["xb"], ws["xc"]
         lanes = self._lanes(dev, K)
-        small = Bn * F_ <= self.inter_matvec_max_seqs          # one utterance: unfused intra pair + lh_inter_matvec (whole-clip rule)
+        # the whole-clip rules of `_separate`, per batch: which intra / inter kernels the windows run
+        unfused_intra = Bn * T < self.fuse_intra_min_frames
+        matvec_inter = Bn * F_ <= self.inter_matvec_max_seqs
         if "kxb" not in ws:                                   # one history-extended K / V pair per block
             z16 = lambda *s_: torch.zeros(*s_, device=dev, dtype=torch.float16)
             ws["kxb"] = [ws["kx"]] + [z16(*ws["kx"].shape) for _ in range(self.n_blocks - 1)]
@@ -645,20 +652,17 @@ class Net(_cabi.HipHost, nn.Module):
                 carry = (1 if k > 0 else 0) | (2 if k + 1 < K else 0)     # inner boundaries: internal cell-state form
                 with lanes.on(k):
                     st = self._stream(dev)
-                    if small:
-                        # one utterance: the window's frames are contiguous — the whole-clip path's unfused intra pair on offsets
-                        o = t0 * F_ * self.emb_dim * 4
-                        oh = t0 * F_ * 2 * self.hidden * 4
-                        lib.call("lh_ln_lstm_intra", P(xa) + o, P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra_w16"]),
-                                 P(bp["intra_b16"]), P(ws["hbuf"]) + oh, Tc, 1, st)
-                        lib.call("lh_linear_res", P(ws["hbuf"]) + oh, P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa) + o,
-                                 P(xb) + o, Tc * F_, 2 * self.hidden, st)
+                    if unfused_intra:
+                        lib.call("lh_ln_lstm_intra_win", P(xa), P(bp["intra_ln_w"]), P(bp["intra_ln_b"]), P(bp["intra_w16"]),
+                                 P(bp["intra_b16"]), P(ws["hbuf"]), Bn, T, t0, Tc, st)
+                        lib.call("lh_linear_res_win", P(ws["hbuf"]), P(bp["intra_lin_w"]), P(bp["intra_lin_b"]), P(xa), P(xb),
+                                 Bn, T, t0, Tc, 2 * self.hidden, st)
                     else:
                         lib.call("lh_intra_block_win", P(xa), P(bp["intra_w16"]), P(bp["intra_b16"]), P(bp["intra_lin_w2"]),
                                  P(bp["intra_lin_b"]), P(xb), Bn, T, t0, Tc, st)
                     if k > 0:
                         lanes.wait(k, ev_r)
-                    if small:
+                    if matvec_inter:
                         lib.call("lh_inter_matvec_win", P(xb), P(bp["inter_s_wih"]), P(bp["inter_s_b"]), P(bp["inter_s_whh"]),
                                  P(bp["inter_lin_w"]), P(bp["inter_lin_b"]), P(hs[i][k]), P(cs[i][k]), P(hs[i][k + 1]),
                                  P(cs[i][k + 1]), P(xc), Bn, T, t0, Tc, carry, st)

@@ -1,4 +1,4 @@
-"""Developer tool (GPU): ms per forward of ONE 5 s utterance over `Net.time_chunks_b1` = K windows, each held bit for bit
+"""Developer tool (GPU): ms per forward of ONE 5 s utterance over `Net.time_chunks_small` = K windows, each held bit for bit
 against the whole-clip forward.   python scripts/time_b1.py [K ...]"""
 import os
 import sys
@@ -31,12 +31,12 @@ def ms(fn, steps=100, warm=10):
 
 
 with torch.no_grad():
-    net.time_chunks_b1 = 1
+    net.time_chunks_small = 1
     y1 = net(mix, emb).clone()
     print("whole clip: %.3f ms" % ms(lambda: net(mix, emb)))
     for K in [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5, 9]:
-        net.time_chunks_b1 = K
+        net.time_chunks_small = K
         same = bool(torch.equal(net(mix, emb), y1))
         print("K = %d  %.3f ms   bit-identical %s   windows %s" % (K, ms(lambda: net(mix, emb)), same, net._window_bounds(1, 625, K)))
-    net.time_chunks_b1 = 1
+    net.time_chunks_small = 1
     print("whole clip: %.3f ms" % ms(lambda: net(mix, emb)))

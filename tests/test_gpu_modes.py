@@ -482,6 +482,7 @@ def test_time_chunks_are_bit_identical_to_the_whole_clip(nets, oracle_cfg_sd):
     d = synth.batch(list(range(8)), 80000)
     mix = d["mixture"].repeat(4, 1, 1).contiguous().to(DEV)
     emb = d["embedding_gt"].repeat(4, 1, 1).contiguous().to(DEV)
+    saved_chunks = net.time_chunks, net.time_chunks_small
     try:
         with torch.no_grad():
             net.time_chunks = 1
@@ -513,25 +514,35 @@ def test_time_chunks_are_bit_identical_to_the_whole_clip(nets, oracle_cfg_sd):
             yz1 = net(mix[:14], emb[:14]).clone()
             net.time_chunks = 2
             assert torch.equal(net(mix[:14], emb[:14]), yz1)
-            # ONE utterance (time_chunks_b1: the latency-bound batch-1 path, windows on multiples of the inter kernel's 64-step
+            # ONE utterance (time_chunks_small: the latency-bound batch-1 path, windows on multiples of the inter kernel's 64-step
             # chunk): 5 s clip in 2 ... 9 windows, bit-identical to the whole clip; then with state in / out
             d1 = synth.batch([77], 80000)
             m1, e1 = d1["mixture"].to(DEV), d1["embedding_gt"].to(DEV)
-            net.time_chunks_b1 = 1
+            net.time_chunks_small = 1
             yw = net(m1, e1).clone()
             for K in (2, 3, 5, 9):
-                net.time_chunks_b1 = K
+                net.time_chunks_small = K
                 assert net._n_time_chunks(1, 625, 1) == K and all(c % 64 == 0 for c in net._window_bounds(1, 625, K)[:-1])
                 for rep in range(2):
                     assert torch.equal(net(m1, e1), yw), (K, rep)
             st1 = O.random_state(cfg, 1, 9)
-            net.time_chunks_b1 = 1
+            net.time_chunks_small = 1
             ya, sa = net.predict(m1, e1[:, 0], to_dev(O.clone_state(st1)), pad=True)
-            net.time_chunks_b1 = 4
+            net.time_chunks_small = 4
             yb, sb = net.predict(m1, e1[:, 0], to_dev(O.clone_state(st1)), pad=True)
             assert torch.equal(ya, yb)
             fa, fb = O.flat_state(sa), O.flat_state(sb)
             for k in fa:
                 assert torch.equal(fa[k], fb[k]), k
+            # the batches in between: 4 utterances (the reference's eval batch: unfused intra pair + the per-sequence inter kernel)
+            # and 8 (unfused intra pair + the tiled inter kernel), two windows against the whole clip
+            for Bm in (4, 8):
+                mm, em = mix[:Bm].contiguous(), emb[:Bm].contiguous()
+                net.time_chunks_small = 1
+                ym = net(mm, em).clone()
+                net.time_chunks_small = 2
+                assert net._n_time_chunks(Bm, 625, 1) == 2
+                for rep in range(2):
+                    assert torch.equal(net(mm, em), ym), (Bm, rep)
     finally:
-        net.time_chunks, net.time_chunks_b1 = 1, 1
+        net.time_chunks, net.time_chunks_small = saved_chunks
