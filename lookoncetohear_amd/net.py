@@ -226,6 +226,7 @@ class Net(_cabi.HipHost, nn.Module):
         #                      windows on multiples of 64 frames: default 2 (one utterance 1.31 -> 1.11 ms per 5 s clip; more
         #                      windows lose again: every hand-over is a cross-stream event of 10-20 us on this runtime).
         # LOOKONCE_TIME_CHUNKS / LOOKONCE_TIME_CHUNKS_SMALL override.
+        self.n_cus = 256                        # MI355X (the library is gfx950-only)
         self.time_chunks = int(os.environ.get("LOOKONCE_TIME_CHUNKS", "0"))
         self.time_chunks_small = int(os.environ.get("LOOKONCE_TIME_CHUNKS_SMALL", "2"))
         self.chunk_min_frames = 64              # >= the 49 frames of attention history: a window then depends on ONE predecessor
@@ -570,11 +571,18 @@ class Net(_cabi.HipHost, nn.Module):
             if Bn * T <= self.stream_intra_max_frames:
                 return 1                                         # a handful of frames: the streaming intra kernel
             K = int(self.time_chunks_small)
+            nseq = Bn * self.n_freqs
+            if nseq <= self.inter_matvec_max_seqs and K > 1:
+                # per-sequence inter kernel (one workgroup per sequence): windows only pay while its last round of workgroups
+                # leaves CUs dark (B = 1: 97 of 256, B = 3: 35, B = 4: 132 -> -14 / -10 / -4 %; B = 2: 194, B = 5: 229 -> +5 / +3 %)
+                tail = nseq % self.n_cus or self.n_cus
+                if tail >= 0.6 * self.n_cus:
+                    K = 1
         else:
             K = int(self.time_chunks)
             if K == 0:                                           # automatic
                 tiles = (Bn * self.n_freqs + 15) // 16           # workgroups (= CUs) of the inter launch
-                K = 2 if tiles < 180 else 1
+                K = 2 if tiles < 0.7 * self.n_cus else 1
             while K > 1 and Bn * (T // K) < self.fuse_intra_min_frames // 2:
                 K -= 1
         return max(min(K, T // max(self.chunk_min_frames, 1)), 1)
