@@ -223,12 +223,14 @@ class Net(_cabi.HipHost, nn.Module):
         #                      -11 % at 20, -5 % at 24, -1 % at 28), one from there on (B = 32: +-0, and the per-launch figures of
         #                      bench.py's roofline object stay those of kernels that run alone); K >= 1 forces K.
         #   time_chunks_small  smaller batches (unfused intra pair; per-sequence inter kernel up to B = 5, tiled one above),
-        #                      windows on multiples of 64 frames: default 2 (one utterance 1.31 -> 1.11 ms per 5 s clip; more
-        #                      windows lose again: every hand-over is a cross-stream event of 10-20 us on this runtime).
+        #                      windows on multiples of the attention tile / of 64 frames.  0 = automatic: 3 windows (B = 6 … 13:
+        #                      -21 … -27 %), 2 for one utterance (1.31 -> 1.12 ms per 5 s clip; every hand-over between windows is
+        #                      a cross-stream event of 10-20 us on this runtime), 1 where the per-sequence kernel's last round of
+        #                      workgroups already fills the chip (B = 2, 5); K >= 1 forces K.
         # LOOKONCE_TIME_CHUNKS / LOOKONCE_TIME_CHUNKS_SMALL override.
         self.n_cus = 256                        # MI355X (the library is gfx950-only)
         self.time_chunks = int(os.environ.get("LOOKONCE_TIME_CHUNKS", "0"))
-        self.time_chunks_small = int(os.environ.get("LOOKONCE_TIME_CHUNKS_SMALL", "2"))
+        self.time_chunks_small = int(os.environ.get("LOOKONCE_TIME_CHUNKS_SMALL", "0"))
         self.chunk_min_frames = 64              # >= the 49 frames of attention history: a window then depends on ONE predecessor
         self._chunk_streams: Dict[str, list] = {}
         self._pack_key = None
@@ -571,13 +573,15 @@ class Net(_cabi.HipHost, nn.Module):
             if Bn * T <= self.stream_intra_max_frames:
                 return 1                                         # a handful of frames: the streaming intra kernel
             K = int(self.time_chunks_small)
-            nseq = Bn * self.n_freqs
-            if nseq <= self.inter_matvec_max_seqs and K > 1:
-                # per-sequence inter kernel (one workgroup per sequence): windows only pay while its last round of workgroups
-                # leaves CUs dark (B = 1: 97 of 256, B = 3: 35, B = 4: 132 -> -14 / -10 / -4 %; B = 2: 194, B = 5: 229 -> +5 / +3 %)
-                tail = nseq % self.n_cus or self.n_cus
-                if tail >= 0.6 * self.n_cus:
-                    K = 1
+            if K == 0:                                           # automatic (profiles/r06h_batch_sweep_windows.txt)
+                nseq = Bn * self.n_freqs
+                K = 3
+                if nseq <= self.inter_matvec_max_seqs:
+                    # per-sequence inter kernel (one workgroup per sequence): windows only pay while its last round of
+                    # workgroups leaves CUs dark (B = 1: 97 of 256, B = 3: 35, B = 4: 132 -> -14 / -14 / -9 %; B = 2: 194,
+                    # B = 5: 229 -> +5 / +3 %); one utterance is best in two (three: 1.18 against 1.12 ms)
+                    tail = nseq % self.n_cus or self.n_cus
+                    K = 1 if tail >= 0.6 * self.n_cus else (2 if nseq <= self.n_cus else 3)
         else:
             K = int(self.time_chunks)
             if K == 0:                                           # automatic
