@@ -209,7 +209,10 @@ class Net(_cabi.HipHost, nn.Module):
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
         self.fuse_intra_min_frames = 8192
-        self.inter_matvec_max_seqs = 512        # inter LSTM: per-sequence workgroups up to two rounds of CUs (batch <= 5)
+        # inter LSTM: one workgroup per sequence (mat-vec recurrence, 0.39 us per step) while the sequences fit ONE round of CUs
+        # (batch <= 2); above, the 16-sequence tile kernel in time windows wins (round 6, profiles/r06h: B = 4 2.27 -> 1.67 ms;
+        # rounds 3-5 used the per-sequence kernel up to two rounds = batch 5).  LOOKONCE_MATVEC_MAX_SEQS overrides.
+        self.inter_matvec_max_seqs = int(os.environ.get("LOOKONCE_MATVEC_MAX_SEQS", "256"))
         self.stream_intra_max_frames = 128      # up to here one workgroup per (frame, direction) still finds its own CU
         # time-axis pipelining of the three blocks (round 6; include/lookonce_hip.h "time windows"): every stage is causal in
         # t, so the frames can be cut into K windows, window k on its own HIP stream, and block i on window k + 1 runs beside
@@ -577,9 +580,9 @@ class Net(_cabi.HipHost, nn.Module):
                 nseq = Bn * self.n_freqs
                 K = 3
                 if nseq <= self.inter_matvec_max_seqs:
-                    # per-sequence inter kernel (one workgroup per sequence): windows only pay while its last round of
-                    # workgroups leaves CUs dark (B = 1: 97 of 256, B = 3: 35, B = 4: 132 -> -14 / -14 / -9 %; B = 2: 194,
-                    # B = 5: 229 -> +5 / +3 %); one utterance is best in two (three: 1.18 against 1.12 ms)
+                    # per-sequence inter kernel (one workgroup per sequence, B <= 2): windows only pay while its workgroups leave
+                    # CUs dark (B = 1: 97 of 256 -> -14 %; B = 2: 194 -> +5 %); one utterance is best in two (three: 1.18 against
+                    # 1.12 ms)
                     tail = nseq % self.n_cus or self.n_cus
                     K = 1 if tail >= 0.6 * self.n_cus else (2 if nseq <= self.n_cus else 3)
         else:

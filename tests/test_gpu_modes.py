@@ -534,9 +534,9 @@ def test_time_chunks_are_bit_identical_to_the_whole_clip(nets, oracle_cfg_sd):
             fa, fb = O.flat_state(sa), O.flat_state(sb)
             for k in fa:
                 assert torch.equal(fa[k], fb[k]), k
-            # the batches in between: 4 utterances (the reference's eval batch: unfused intra pair + the per-sequence inter kernel)
-            # and 8 (unfused intra pair + the tiled inter kernel), two windows against the whole clip
-            for Bm in (4, 8):
+            # the batches in between: 2 utterances (unfused intra pair + the per-sequence inter kernel, two windows forced), 4 (the
+            # reference's eval batch) and 8 (unfused intra pair + the tiled inter kernel), against the whole clip
+            for Bm in (2, 4, 8):
                 mm, em = mix[:Bm].contiguous(), emb[:Bm].contiguous()
                 net.time_chunks_small = 1
                 ym = net(mm, em).clone()
