@@ -208,7 +208,10 @@ class Net(_cabi.HipHost, nn.Module):
         self._range_flags: Dict[str, torch.Tensor] = {}
         # fused LSTM + Linear + residual kernels (f16x3 mode only); LOOKONCE_FUSE=0 selects the unfused pair
         self.fuse_linear = os.environ.get("LOOKONCE_FUSE", "1") != "0"
-        self.fuse_intra_min_frames = 8192
+        # fused intra kernel (two launches, one per direction) from here on, the unfused pair (both directions concurrently) below:
+        # 8192 frames in rounds 1-5; with time windows the crossover is lower (profiles/r06h: B = 13 x 625 frames 3.40 -> 3.08 ms,
+        # B = 10 2.66 -> 2.60, B = 8 2.32 -> 2.36)
+        self.fuse_intra_min_frames = int(os.environ.get("LOOKONCE_FUSE_INTRA_MIN_FRAMES", "6000"))
         # inter LSTM: one workgroup per sequence (mat-vec recurrence, 0.39 us per step) while the sequences fit ONE round of CUs
         # (batch <= 2); above, the 16-sequence tile kernel in time windows wins (round 6, profiles/r06h: B = 4 2.27 -> 1.67 ms;
         # rounds 3-5 used the per-sequence kernel up to two rounds = batch 5).  LOOKONCE_MATVEC_MAX_SEQS overrides.
@@ -221,7 +224,7 @@ class Net(_cabi.HipHost, nn.Module):
         # slower one still reads); the output is bit-identical to the whole-clip forward.  What it buys depends on how much of
         # the chip one launch fills (profiles/r06b, r06e, r06h): the inter LSTM is a 625-step dependent chain on ceil(97 B / 16)
         # CUs, and every small-batch launch is latency-bound —
-        #   time_chunks        batches on the fused kernels (B T >= 8192 frames: B >= 14 at 5 s).  0 = automatic: 2 windows while
+        #   time_chunks        batches on the fused kernels (B T >= 6000 frames: B >= 10 at 5 s).  0 = automatic: 2 windows while
         #                      the inter launch leaves more than ~30 % of the 256 CUs dark (B <= 29: -19 % at B = 14, -15 % at 16,
         #                      -11 % at 20, -5 % at 24, -1 % at 28), one from there on (B = 32: +-0, and the per-launch figures of
         #                      bench.py's roofline object stay those of kernels that run alone); K >= 1 forces K.

@@ -74,7 +74,7 @@ def test_streaming_chunks_and_mod_pad(emu_net, oracle_cfg_sd):
 
 def test_fused_intra_path_forced_small(emu_net, oracle_cfg_sd):
     """The large-batch intra path (k_intra_xp, lh_recur.hip: LSTM + Linear + residual fused, x half of the gates one step
-    ahead, hand-ordered step; forward launch then accumulating reverse launch), which `Net` only selects from 8192 frames
+    ahead, hand-ordered step; forward launch then accumulating reverse launch), which `Net` only selects from 6000 frames (8192 before round 6)
     on, forced at a tiny size: 38 frames = 3 sequence tiles, last one ragged."""
     cfg, sd = oracle_cfg_sd
     B, T = 2, 19
@@ -234,7 +234,7 @@ def test_unfused_inter_path_with_32_sequence_tiles(emu_net, oracle_cfg_sd):
 
 
 def test_tiled_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
-    """The mid-size intra path (lh_ln_lstm_intra: 16-sequence MFMA tiles + lh_linear_res, used between 128 and 8192
+    """The mid-size intra path (lh_ln_lstm_intra: 16-sequence MFMA tiles + lh_linear_res, used between 128 and 6000 (8192 before round 6)
     frames) forced at a size where `Net` would pick the streaming mat-vec kernel."""
     cfg, sd = oracle_cfg_sd
     d = synth.batch([6], 128 * 5 + 64)

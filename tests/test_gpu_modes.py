@@ -104,7 +104,7 @@ def test_all_fp32_mode_on_the_goldens(nets, golden, oracle_cfg_sd):
 
 
 def test_ragged_batch14_all_modes_agree_with_oracle(nets, oracle_cfg_sd):
-    """B = 14 x 5 s: the smallest batch on the fused intra path (B*T = 8750 >= 8192, not a multiple of the 16-sequence
+    """B = 14 x 5 s: a small batch on the fused intra path (B*T = 8750: fused from 6000 frames on since round 6, 8192 before; not a multiple of the 16-sequence
     tile; 1358 inter sequences = 84 tiles + 14) — and the shape at which the other two modes switch to their
     32-sequence tilings (k_ln_lstm<2>, k_ln_lstm_h3<2> + remainder launch).  All three modes against each other on
     every row, two rows against the CPU oracle."""
