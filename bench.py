@@ -655,7 +655,7 @@ def secondary_measurements(net, dev, mix8, emb8):
             try:
                 mix = mix8.repeat((B + 7) // 8, 1, 1)[:B].contiguous()
                 emb = emb8.repeat((B + 7) // 8, 1, 1)[:B].contiguous()
-                ms = _time_forward(lambda: net(mix, emb), 5 if B == 1 else 3, 2)
+                ms = _time_forward(lambda: net(mix, emb), 50 if B == 1 else 3, 5 if B == 1 else 2)
                 # rows 0..3 (B = 256) / row 0 (B = 1) = utterances 0..3, the clips of the cpu_baseline leg: held against its
                 # reference outputs once that leg has run (`secondary_parity`)
                 out[f"_y_offline_b{B}"] = net(mix, emb)[:4].cpu()
