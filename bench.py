@@ -11,6 +11,7 @@ an RCCL all-reduce of those 4 sums.  Workload at N=1: BASELINE.json configs[2] (
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (no launcher: bench.py starts the N ranks itself, `self_launch`)
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (largest share of GPU time in the
 timed region), measured live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a port

@@ -111,6 +111,10 @@ timelines)          # dispatch timelines of one step (scripts/rocpd_summary.py -
     cd $R
     timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
     cut -c1-400 gpurun_out/bench.json; tail -3 gpurun_out/step_timeline_*.txt ;;
+sweep)              # the separator over the batch size, whole-clip launches against the default time windows (scripts/batch_sweep.py)
+    for cfg in "1 1" "0 0"; do set -- $cfg; echo "time_chunks $1 time_chunks_small $2"
+        LOOKONCE_TIME_CHUNKS=$1 LOOKONCE_TIME_CHUNKS_SMALL=$2 python scripts/batch_sweep.py ${SWEEP_B:-} 2>&1 | grep "B ="
+    done | tee gpurun_out/batch_sweep.txt ;;
 chunks)             # Net.time_chunks: the bit-identity test, then same-box A/B of the default line over K (REPS x K in "1 2 3 4")
     timeout 600 python -m pytest tests/test_gpu_modes.py -m gpu -x -q -k "time_chunks" 2>&1 | tail -5 | tee gpurun_out/pytest_chunks.txt
     for rep in $(seq ${REPS:-2}); do for k in ${KS:-1 2 3 4}; do
