@@ -380,6 +380,16 @@ int lh_emb_axis_fused(const float* x, const void* wrec_pk, const float* brec, co
                       void* xsplit, void* hsplit, float* out, int B, int T, int inter, int have_xsplit, int emit_split,
                       lh_stream_t stream);
 
+/* The inter axis for SMALL batches (ABI 14): as lh_emb_axis_fused(inter = 1) with the recurrence on one workgroup per (sequence,
+ * direction) — the quad-lane mat-vec step of the separator's batch-1 kernels, 0.39 us per step against 1.4 us for a 16-sequence
+ * tile that a single enrollment fills with 9 workgroups.  Same result to fp32 rounding.
+ *   wih_pk  fp16 hi/lo B image [2 dirs x 16 ntiles][8 ksteps][64 lanes][16] of W_ih' [256 x 256] (LayerNorm gamma folded, K = window
+ *           slot*64 + channel in natural tap order, columns (direction, unit, gate));  bih [2][256] same column order
+ *           (b_ih + b_hh + W_ih beta);  whh fp32 [2][256][64], row 4 unit + gate;  the rest as lh_emb_axis_fused */
+int lh_emb_axis_mv(const float* x, const void* wih_pk, const float* bih, const float* whh, const void* wct_pk,
+                   const float* bct, void* xsplit, void* hsplit, float* out, int B, int T, int have_xsplit, int emit_split,
+                   lh_stream_t stream);
+
 /* Enrollment embedder, attention branch of one GridNetBlock (espnet2 GridNetBlock.forward attention part, restated in
  * oracle/embedder_oracle.py:149-168): per-head Q/K/V 1x1 conv + PReLU + LayerNorm over (channel, bin), full T x T
  * softmax attention per (head, utterance), head merge, attn_concat_proj (1x1 conv + PReLU + LayerNorm) + residual.

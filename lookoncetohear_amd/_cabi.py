@@ -46,6 +46,7 @@ SIGNATURES = {
     "lh_proj_ln_res_win": [_P] * 9 + [_I, _I, _I, _I, _P],
     "lh_emb_frontend": [_P] * 10 + [_I, _I, _I, _P],
     "lh_emb_axis_fused": [_P] * 8 + [_I, _I, _I, _I, _I, _P],
+    "lh_emb_axis_mv": [_P] * 9 + [_I, _I, _I, _I, _P],
     "lh_emb_attn_block": [_P] * 24 + [_I, _I, _P],
     "lh_emb_head": [_P] * 7 + [_I, _I, _P],
     "lh_render_binaural": [_P] * 8 + [_I, _I, _I, _I, _P],

@@ -136,7 +136,7 @@ def build_hip(force: bool = False, verbose: bool = True, extra_flags=(), out: st
     """`extra_flags` / `out`: A/B variants of the same sources (e.g. -DLH_ACT_MERGED=1) built next to the product
     library and selected with LOOKONCE_HIP_LIB (scripts/gpu_ab.sh); the product build uses the defaults."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "lh_common.h"), os.path.join(CSRC, "lh_split.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "lh_common.h"), os.path.join(CSRC, "lh_split.h"), os.path.join(CSRC, "lh_quad.h"),
                                                        os.path.join(os.path.dirname(PKG), "include", "lookonce_hip.h")]
     if not force and _newer(out, deps):
         return out

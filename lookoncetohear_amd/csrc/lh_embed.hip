@@ -6,6 +6,7 @@
 //   k_emb_head / k_emb_head_mean                   Linear(65*64 -> 256) + LayerNorm + mean over frames
 // Activations are channel-last [B][T][65][64] like the separator's.
 #include "lh_common.h"
+#include "lh_quad.h"
 
 namespace lh {
 
@@ -848,6 +849,122 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
     }
     if (it < P) step(it, stA, std::integral_constant<int, 0>{});
     if (!loader) flush_h(P - 1, P & 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the INTER-axis recurrence for SMALL batches, one workgroup per (sequence, direction).  The tiled kernel above needs
+// 16 sequences per workgroup: one enrollment clip is 65 x 2 / 16 = 9 workgroups walking 1248 dependent steps at ~1.4 us each —
+// 1.75 ms per block, 5.2 of the 5.6 ms a single 5 s enrollment took, with 247 CUs dark.  Here every (sequence, direction) gets
+// its own CU and the step is the quad-lane 256 x 64 mat-vec of the separator's batch-1 kernels (lh_quad.h: 0.39 us per step);
+// the time axis is cut into chunks of 64 steps whose 256-wide input half (the unfold's four window slots x 64 channels, taps =
+// row offsets into the staged position rows like k_emb_gx) runs as a split-precision MFMA GEMM in front of the chunk's
+// recurrence; the chunk's hidden states leave as fp16 hi | lo rows (k_emb_convt2's operand format).  The reverse direction walks
+// the natural positions downwards (weights in natural tap order: embed_net.py `_pack_axis`, not pack_rec's mirrored form).
+//   xs      pre-split LayerNorm(x) images (k_emb_lnsplit / emit_split), rows_x rows of 64 halves, hi then lo
+//   wih_pk  fp16 hi/lo B image [2 dirs x 16 ntiles][8 ksteps][64 lanes][16] of W_ih' (LN gamma folded), K = slot*64 + channel,
+//           columns (direction, unit, gate);  bih [2][256] in the same column order (b_ih + b_hh + W_ih beta)
+//   whh     fp32 [2][256][64], row 4 unit + gate
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int MV_TC = 64;                          // steps per chunk
+constexpr int MV_ROWS = MV_TC + EKS - 1;           // 67 position rows per chunk
+constexpr int MV_RP = 81;                          // odd row pitch of the staged rows (16-byte slots), like k_emb_gx
+constexpr int MV_HP = H + 8;                       // fp16 row pitch of the chunk's hidden states (144 B: 16-byte aligned rows)
+
+__global__ void __launch_bounds__(IS_NT) k_emb_inter_mv(const _Float16* __restrict__ xs, const _Float16* __restrict__ wih_pk,
+                                                        const float* __restrict__ bih, const float* __restrict__ whh,
+                                                        _Float16* __restrict__ hs, int nseq, int P, int T, long rows_x) {
+    __shared__ __attribute__((aligned(16))) _Float16 ahi[8 * MV_RP * 8];
+    __shared__ __attribute__((aligned(16))) _Float16 alo[8 * MV_RP * 8];
+    __shared__ __attribute__((aligned(16))) float gxs[MV_TC * IS_GP];      // input half of the gates, [step][column 4 u + g]
+    __shared__ __attribute__((aligned(16))) _Float16 hh[MV_TC * MV_HP];    // h of the chunk's steps, hi | lo
+    __shared__ __attribute__((aligned(16))) _Float16 hl[MV_TC * MV_HP];
+    __shared__ __attribute__((aligned(16))) float hprev[2][H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(tid), g4 = lane >> 4, l15 = lane & 15;
+    const int seq = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int L = P + EKS - 1;
+    const long hrows = (long)nseq * P;
+    const _Float16* xh = xs;
+    const _Float16* xl = xs + rows_x * C;
+
+    const int unit = (tid & (IS_NR - 1)) >> 2, qs = tid & 3;             // recurrence role (threads < 256): unit, k slice
+    f32x2 wr[4][8];
+    quad_load_w(whh + (long)dir * IS_GP * H, unit, qs, wr);
+    const bool cell_lane = qs == 1 && tid < IS_NR;
+    const float gscale = quad_gate_scale(qs);
+    float c = 0.f;                                                         // QS_K2 x cell state; the embedder carries none
+    if (tid < H) hprev[0][tid] = 0.f;
+    int hb = 0;
+
+    const int nchunk = (P + MV_TC - 1) / MV_TC;
+    for (int ci = 0; ci < nchunk; ++ci) {
+        // natural steps [p0, p0 + n) of this chunk; the reverse direction takes its chunks (and their steps) from the end
+        const int p0 = dir ? max(P - (ci + 1) * MV_TC, 0) : ci * MV_TC;
+        const int n = dir ? (P - ci * MV_TC) - p0 : min(MV_TC, P - p0);
+        // ---- stage position rows p0 .. p0 + n + 2 (16-byte copies of the pre-split images)
+        for (int e = tid; e < MV_ROWS * 8; e += IS_NT) {
+            const long off = pos_row<true>(seq, min(p0 + (e >> 3), L - 1), T) * C + (e & 7) * 8;
+            const int idx = ((e & 7) * MV_RP + (e >> 3)) * 8;
+            *reinterpret_cast<f16x8*>(&ahi[idx]) = *reinterpret_cast<const f16x8*>(&xh[off]);
+            *reinterpret_cast<f16x8*>(&alo[idx]) = *reinterpret_cast<const f16x8*>(&xl[off]);
+        }
+        __syncthreads();
+        // ---- G_x[step][col] = b[col] + sum_{slot, c} xhat[step + slot][c] W'[col][slot*64 + c]: wave w owns column tiles 2w, 2w+1
+#pragma unroll 1
+        for (int i = 0; i < 16 / IS_NW; ++i) {
+            const int nt = (16 / IS_NW) * wave + i;
+            f16x8 wh[8], wl[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const _Float16* p = wih_pk + ((long)((dir * 16 + nt) * 8 + ks) * 64 + lane) * 16;
+                wh[ks] = *reinterpret_cast<const f16x8*>(p);
+                wl[ks] = *reinterpret_cast<const f16x8*>(p + 8);
+            }
+            const float bz = bih[dir * IS_GP + nt * 16 + l15];
+#pragma unroll 1
+            for (int m = 0; m < MV_TC / 16; ++m) {
+                f32x4 am = f32x4{bz, bz, bz, bz}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int idx = (((ks & 1) * 4 + g4) * MV_RP + m * 16 + l15 + (ks >> 1)) * 8;
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
+                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
+                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
+                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gxs[(m * 16 + g4 * 4 + r) * IS_GP + nt * 16 + l15] = am[r] + ac[r];
+            }
+        }
+        __syncthreads();
+        // ---- recurrence over the chunk's steps (lh_quad.h); h_t also goes into the chunk's fp16 rows
+        if (tid >= IS_NR) {
+            for (int j = 0; j < n; ++j) QS_SYNC();
+            hb ^= n & 1;
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const int row = dir ? n - 1 - j : j;                         // natural step p0 + row
+                const float gx = gscale * gxs[row * IS_GP + tid];
+                const float hv = quad_step(wr, hprev[hb] + 16 * qs, gx, c, qs);
+                if (cell_lane) {
+                    hprev[hb ^ 1][unit] = hv;
+                    _Float16 th, tl;
+                    split_hl(hv, th, tl);
+                    hh[row * MV_HP + unit] = th;
+                    hl[row * MV_HP + unit] = tl;
+                }
+                hb ^= 1;
+                QS_SYNC();
+            }
+        }
+        // ---- the chunk's hidden states: hi | lo images [row][128], this direction's 64 columns, 16-byte pieces
+        for (int e = tid; e < n * 16; e += IS_NT) {
+            const int row = e >> 4, piece = e & 15;
+            _Float16* dst = hs + (piece < 8 ? 0 : hrows * 128) + ((long)seq * P + p0 + row) * 128 + dir * H + (piece & 7) * 8;
+            *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&(piece < 8 ? hh : hl)[row * MV_HP + (piece & 7) * 8]);
+        }
+        __syncthreads();                                                     // hh / hl / gxs / the staged rows are rewritten
+    }
 }
 
 // out[r] = x[r] + b + sum_{k<4} Wt_k h[(s, q - k)]: ConvTranspose1d(128 -> 64, 4, stride 1) + residual from k_emb_rec's
@@ -1880,6 +1997,31 @@ extern "C" int lh_emb_axis_fused(const float* x, const void* wrec_pk, const floa
         hipLaunchKernelGGL((k_emb_convt2<false>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
                            (const _Float16*)wct_pk, bct, x, out, xs_next, rows, nseq, P, T);
     }
+    return check_launch();
+}
+
+// The inter-axis path for SMALL batches (round 6): as lh_emb_axis_fused(inter = 1), with the recurrence on one workgroup per
+// (sequence, direction) — k_emb_inter_mv — instead of 16-sequence tiles.  Same results to fp32 rounding (the input half is the
+// same split-precision product in another summation order, the recurrent half an fp32 mat-vec instead of three fp16 MFMAs).
+//   wih_pk, bih   the `_pack_axis` images of embed_net.py (natural tap order, columns (direction, unit, gate), unscaled)
+//   whh           fp32 [2][256][64], row 4 unit + gate
+extern "C" int lh_emb_axis_mv(const float* x, const void* wih_pk, const float* bih, const float* whh, const void* wct_pk,
+                              const float* bct, void* xsplit, void* hsplit, float* out, int B, int T, int have_xsplit,
+                              int emit_split, lh_stream_t stream) {
+    using namespace lh;
+    if (!x || !wih_pk || !bih || !whh || !wct_pk || !bct || !xsplit || !hsplit || !out || B <= 0 || T < EKS || x == out)
+        return LH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nseq = B * EF, P = T - (EKS - 1);
+    const long rows = (long)B * T * EF;
+    const long lnb = (rows + 15) / 16;
+    const int ctiles = nseq * ((T + CtShape<true>::RT - 1) / CtShape<true>::RT);
+    if (!have_xsplit)
+        hipLaunchKernelGGL(k_emb_lnsplit, dim3((unsigned)(lnb < 4096 ? lnb : 4096)), dim3(256), 0, st, x, (_Float16*)xsplit, rows);
+    hipLaunchKernelGGL(k_emb_inter_mv, dim3(2 * nseq), dim3(IS_NT), 0, st, (const _Float16*)xsplit, (const _Float16*)wih_pk, bih,
+                       whh, (_Float16*)hsplit, nseq, P, T, rows);
+    hipLaunchKernelGGL((k_emb_convt2<true>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
+                       (const _Float16*)wct_pk, bct, x, out, emit_split ? (_Float16*)xsplit : nullptr, rows, nseq, P, T);
     return check_launch();
 }
 

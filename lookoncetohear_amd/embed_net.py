@@ -84,6 +84,9 @@ class EmbedTFGridNet(_cabi.HipHost, nn.Module):
         # library does not contain it and the call fails loudly)
         self.fused_axis = os.environ.get("LOOKONCE_EMB_FUSED", "1") != "0"
         self.n_streams = int(os.environ.get("LOOKONCE_EMB_STREAMS", "2"))
+        # inter-axis recurrence: one workgroup per (sequence, direction) (k_emb_inter_mv: 0.39 us per step) while those fit this
+        # many workgroups, 16-sequence tiles (k_emb_rec: ~1.4 us per step) above.  LOOKONCE_EMB_MV_MAX_WGS overrides.
+        self.inter_mv_max_wgs = int(os.environ.get("LOOKONCE_EMB_MV_MAX_WGS", "512"))
         self._side = None
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: (C-ABI call, start event, end event) per launch
@@ -179,6 +182,8 @@ class EmbedTFGridNet(_cabi.HipHost, nn.Module):
                             tag = name + (".inter" if args[12] else ".intra")
                         elif name == "lh_emb_axis_fused":
                             tag = "lh_emb_axis" + (".inter" if args[10] else ".intra")
+                        elif name == "lh_emb_axis_mv":
+                            tag = "lh_emb_axis.inter"
                         prof.append((tag, e0, e1))
             za, zb, zc = e(B, T, F_, C_), e(B, T, F_, C_), e(B, T, F_, C_)
             inv_std = e(B)
@@ -205,8 +210,13 @@ class EmbedTFGridNet(_cabi.HipHost, nn.Module):
                     # block's intra call, the front end's GroupNorm pass for block 0
                     lib.call("lh_emb_axis_fused", P(za), P(bp["intra_wrec"]), P(bp["intra_brec"]), P(bp["intra_wct"]),
                              P(bp["intra_bct"]), P(xsp), P(hbuf), P(zb), B, T, 0, 1, 1, st)
-                    lib.call("lh_emb_axis_fused", P(zb), P(bp["inter_wrec"]), P(bp["inter_brec"]), P(bp["inter_wct"]),
-                             P(bp["inter_bct"]), P(xsp), P(hbuf), P(zc), B, T, 1, 1, 0, st)
+                    if 2 * B * F_ <= self.inter_mv_max_wgs:
+                        # few sequences: one workgroup per (sequence, direction), mat-vec recurrence (k_emb_inter_mv)
+                        lib.call("lh_emb_axis_mv", P(zb), P(bp["inter_wih"]), P(bp["inter_bih"]), P(bp["inter_whh_mv"]),
+                                 P(bp["inter_wct"]), P(bp["inter_bct"]), P(xsp), P(hbuf), P(zc), B, T, 1, 0, st)
+                    else:
+                        lib.call("lh_emb_axis_fused", P(zb), P(bp["inter_wrec"]), P(bp["inter_brec"]), P(bp["inter_wct"]),
+                                 P(bp["inter_bct"]), P(xsp), P(hbuf), P(zc), B, T, 1, 1, 0, st)
                 else:
                     lib.call("lh_emb_axis", P(za), P(bp["intra_wih"]), P(bp["intra_bih"]), P(bp["intra_whh"]), P(bp["intra_wct"]),
                              P(bp["intra_bct"]), P(xsp), P(gx), P(hbuf), P(zb), B, T, 0, st)
@@ -290,13 +300,14 @@ def _pack_axis(sd, pre, ax):
     (c*4 + k) to window-major (k*64 + c), output columns reordered to (direction, unit, gate)."""
     g = lambda k: sd[pre + k].double()
     lw, lb = g(f"{ax}_norm.gamma").reshape(-1), g(f"{ax}_norm.beta").reshape(-1)
-    ws, bs = [], []
+    ws, bs, hh = [], [], []
     for sfx in ("", "_reverse"):
         w = g(f"{ax}_rnn.weight_ih_l0{sfx}").reshape(256, 64, 4)                 # [col, c, k]
         b = g(f"{ax}_rnn.bias_ih_l0{sfx}") + g(f"{ax}_rnn.bias_hh_l0{sfx}") + (w * lb[None, :, None]).sum((1, 2))
         w = (w * lw[None, :, None]).permute(0, 2, 1).reshape(256, 256)           # [col, k*64 + c]
         perm = (torch.arange(4, device=w.device)[None, :] * 64 + torch.arange(64, device=w.device)[:, None]).reshape(-1)  # new unit*4+gate <- gate*64+unit
         ws.append(w[perm]); bs.append(b[perm])
+        hh.append(g(f"{ax}_rnn.weight_hh_l0{sfx}")[perm].float())               # rows 4 unit + gate (lh_quad.h quad_load_w)
     out = {
         f"{ax}_wih": pack_linear_f16x3(torch.cat(ws, 0).float()), f"{ax}_bih": torch.cat(bs).float().contiguous(),
         f"{ax}_whh": torch.stack([_pack_whh_f16x3(sd[pre + f"{ax}_rnn.weight_hh_l0"]),
@@ -304,6 +315,7 @@ def _pack_axis(sd, pre, ax):
         f"{ax}_wct": pack_linear_f16x3(sd[pre + f"{ax}_linear.weight"].permute(1, 2, 0).reshape(64, 512).float().contiguous()),
         f"{ax}_bct": sd[pre + f"{ax}_linear.bias"].float().contiguous(),
     }
+    out[f"{ax}_whh_mv"] = torch.stack(hh).contiguous()                           # fp32 [2][256][64]: k_emb_inter_mv
     out[f"{ax}_wrec"], out[f"{ax}_brec"] = pack_rec(sd, pre, ax)
     return out
 

@@ -16,7 +16,7 @@ def build_emu(force=False, extra_flags=(), out=OUT):
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = "clang++"
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "lh_common.h"), os.path.join(CSRC, "lh_split.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "lh_common.h"), os.path.join(CSRC, "lh_split.h"), os.path.join(CSRC, "lh_quad.h"),
                                                        os.path.join(HERE, "include", "hip", "hip_runtime.h"),
                                                        os.path.join(ROOT, "include", "lookonce_hip.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
