@@ -856,7 +856,7 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
 // 16 sequences per workgroup: one enrollment clip is 65 x 2 / 16 = 9 workgroups walking 1248 dependent steps at ~1.4 us each —
 // 1.75 ms per block, 5.2 of the 5.6 ms a single 5 s enrollment took, with 247 CUs dark.  Here every (sequence, direction) gets
 // its own CU and the step is the quad-lane 256 x 64 mat-vec of the separator's batch-1 kernels (lh_quad.h: 0.39 us per step);
-// the time axis is cut into chunks of 64 steps whose 256-wide input half (the unfold's four window slots x 64 channels, taps =
+// the time axis is cut into chunks of 32 steps whose 256-wide input half (the unfold's four window slots x 64 channels, taps =
 // row offsets into the staged position rows like k_emb_gx) runs as a split-precision MFMA GEMM in front of the chunk's
 // recurrence; the chunk's hidden states leave as fp16 hi | lo rows (k_emb_convt2's operand format).  The reverse direction walks
 // the natural positions downwards (weights in natural tap order: embed_net.py `_pack_axis`, not pack_rec's mirrored form).
@@ -865,12 +865,15 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
 //           columns (direction, unit, gate);  bih [2][256] in the same column order (b_ih + b_hh + W_ih beta)
 //   whh     fp32 [2][256][64], row 4 unit + gate
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int MV_TC = 64;                          // steps per chunk
-constexpr int MV_ROWS = MV_TC + EKS - 1;           // 67 position rows per chunk
-constexpr int MV_RP = 81;                          // odd row pitch of the staged rows (16-byte slots), like k_emb_gx
+// Two workgroups per CU (52 KB of LDS, <= 128 registers): the recurrence only occupies one wave per SIMD and is latency, not
+// issue — a second sequence on the same CU costs little, and 2 x 256 resident workgroups take 2 B 65 <= 512 (B <= 3) in ONE round
+// (B = 2 is 260 workgroups: with one per CU a second round for FOUR of them doubled the pass).
+constexpr int MV_TC = 32;                          // steps per chunk
+constexpr int MV_ROWS = MV_TC + EKS - 1;           // 35 position rows per chunk
+constexpr int MV_RP = 41;                          // odd row pitch of the staged rows (16-byte slots), like k_emb_gx
 constexpr int MV_HP = H + 8;                       // fp16 row pitch of the chunk's hidden states (144 B: 16-byte aligned rows)
 
-__global__ void __launch_bounds__(IS_NT) k_emb_inter_mv(const _Float16* __restrict__ xs, const _Float16* __restrict__ wih_pk,
+__global__ void __launch_bounds__(IS_NT, 2) k_emb_inter_mv(const _Float16* __restrict__ xs, const _Float16* __restrict__ wih_pk,
                                                         const float* __restrict__ bih, const float* __restrict__ whh,
                                                         _Float16* __restrict__ hs, int nseq, int P, int T, long rows_x) {
     __shared__ __attribute__((aligned(16))) _Float16 ahi[8 * MV_RP * 8];
@@ -908,33 +911,35 @@ __global__ void __launch_bounds__(IS_NT) k_emb_inter_mv(const _Float16* __restri
             *reinterpret_cast<f16x8*>(&alo[idx]) = *reinterpret_cast<const f16x8*>(&xl[off]);
         }
         __syncthreads();
-        // ---- G_x[step][col] = b[col] + sum_{slot, c} xhat[step + slot][c] W'[col][slot*64 + c]: wave w owns column tiles 2w, 2w+1
+        // ---- G_x[step][col] = b[col] + sum_{slot, c} xhat[step + slot][c] W'[col][slot*64 + c]: wave w owns column tiles 2w, 2w+1;
+        //      k-step outermost with the chunk's row tiles as accumulators: every weight fragment is fetched (L2) once per chunk and
+        //      only one k-step of them is live (the 128-register budget of two workgroups per CU)
 #pragma unroll 1
         for (int i = 0; i < 16 / IS_NW; ++i) {
             const int nt = (16 / IS_NW) * wave + i;
-            f16x8 wh[8], wl[8];
+            const float bz = bih[dir * IS_GP + nt * 16 + l15];
+            f32x4 am[MV_TC / 16], ac[MV_TC / 16];
 #pragma unroll
+            for (int m = 0; m < MV_TC / 16; ++m) { am[m] = f32x4{bz, bz, bz, bz}; ac[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
             for (int ks = 0; ks < 8; ++ks) {
                 const _Float16* p = wih_pk + ((long)((dir * 16 + nt) * 8 + ks) * 64 + lane) * 16;
-                wh[ks] = *reinterpret_cast<const f16x8*>(p);
-                wl[ks] = *reinterpret_cast<const f16x8*>(p + 8);
-            }
-            const float bz = bih[dir * IS_GP + nt * 16 + l15];
-#pragma unroll 1
-            for (int m = 0; m < MV_TC / 16; ++m) {
-                f32x4 am = f32x4{bz, bz, bz, bz}, ac = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(p);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(p + 8);
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
+                for (int m = 0; m < MV_TC / 16; ++m) {
                     const int idx = (((ks & 1) * 4 + g4) * MV_RP + m * 16 + l15 + (ks >> 1)) * 8;
                     const f16x8 ah = *reinterpret_cast<const f16x8*>(&ahi[idx]);
                     const f16x8 al = *reinterpret_cast<const f16x8*>(&alo[idx]);
-                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[ks], am, 0, 0, 0);
-                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[ks], ac, 0, 0, 0);
-                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[ks], ac, 0, 0, 0);
+                    am[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, am[m], 0, 0, 0);
+                    ac[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, ac[m], 0, 0, 0);
+                    ac[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, ac[m], 0, 0, 0);
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gxs[(m * 16 + g4 * 4 + r) * IS_GP + nt * 16 + l15] = am[r] + ac[r];
             }
+#pragma unroll
+            for (int m = 0; m < MV_TC / 16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gxs[(m * 16 + g4 * 4 + r) * IS_GP + nt * 16 + l15] = am[m][r] + ac[m][r];
         }
         __syncthreads();
         // ---- recurrence over the chunk's steps (lh_quad.h); h_t also goes into the chunk's fp16 rows
