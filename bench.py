@@ -299,7 +299,7 @@ def secondary_parity(sec, kept, ref):
         return {"max_abs": ma, "d_sisnri_db": ds, "clips": k, "against": "reference ATen sequence fp32 (this run's cpu_baseline leg)",
                 "tolerance": {"max_abs": 1e-3, "d_sisnri_db": 0.05}, "ok": bool(ma <= 1e-3 and ds <= 0.05)}
 
-    for key, leg in (("_y_offline_b1", "offline_b1"), ("_y_offline_b256", "offline_b256"),
+    for key, leg in (("_y_offline_b1", "offline_b1"), ("_y_offline_b4", "offline_b4"), ("_y_offline_b256", "offline_b256"),
                      ("_y_two_in_flight", "offline_b32_two_in_flight")):
         if key in kept and isinstance(sec.get(leg), dict):
             sec[leg]["parity"] = obj(kept[key])
@@ -652,18 +652,20 @@ def secondary_measurements(net, dev, mix8, emb8):
     out = {}
     log = lambda m: print(f"[bench secondary] {m}", file=sys.stderr, flush=True)
     with torch.no_grad():
-        for B in (1, 256):
+        for B in (1, 4, 256):
             try:
                 mix = mix8.repeat((B + 7) // 8, 1, 1)[:B].contiguous()
                 emb = emb8.repeat((B + 7) // 8, 1, 1)[:B].contiguous()
-                ms = _time_forward(lambda: net(mix, emb), 50 if B == 1 else 3, 5 if B == 1 else 2)
+                ms = _time_forward(lambda: net(mix, emb), 50 if B <= 4 else 3, 5 if B <= 4 else 2)
                 # rows 0..3 (B = 256) / row 0 (B = 1) = utterances 0..3, the clips of the cpu_baseline leg: held against its
                 # reference outputs once that leg has run (`secondary_parity`)
                 out[f"_y_offline_b{B}"] = net(mix, emb)[:4].cpu()
                 out[f"offline_b{B}"] = {"ms_per_step": ms, "frames_per_s": B * FRAMES_PER_CLIP / ms * 1e3,
                                         "rtf": ms * 1e-3 / (B * CLIP_SECONDS),
+                                        "time_windows": net._n_time_chunks(B, FRAMES_PER_CLIP, 1),
                                         "workload": f"{B} x 5 s clips, offline forward" +
-                                                    (" (BASELINE configs[3]'s global batch on one GPU)" if B == 256 else "")}
+                                                    (" (BASELINE configs[3]'s global batch on one GPU)" if B == 256 else "") +
+                                                    (" (the reference's eval batch, src/ts_hear_test.py:121)" if B == 4 else "")}
                 log(f"offline B={B}: {ms:.3f} ms")
                 del mix, emb
             except Exception as e:          # e.g. out of memory on a smaller part: report, do not lose the headline line
@@ -788,11 +790,17 @@ def secondary_measurements(net, dev, mix8, emb8):
             x = mix8.repeat(8, 1, 1).contiguous()
             ms = _time_forward(lambda: enet(x), 2, 1)
             out["_embed_b64_rows"] = enet(x)[:2].cpu()           # rows 0, 1 = utterances 0, 1: the cpu leg re-computes the first
+            small = {}
+            for Bs in (1, 4):                                    # one enrollment / the reference's eval batch (round 6: k_emb_inter_mv)
+                xs_ = x[:Bs].contiguous()
+                small[str(Bs)] = _time_forward(lambda: enet(xs_), 10, 3)
+                log(f"embed B={Bs}: {small[str(Bs)]:.3f} ms")
             kern_e = embed_instrumented_step(enet, x)
             out["embed_b64"] = {"ms_per_step": ms, "clips_per_s": B / ms * 1e3, "frames_per_s": B * 1251 / ms * 1e3,
                                 "workload": "BASELINE configs[4]: configs/embed.json embedder, 64 x 5 s clips (random-init "
                                             "weights; oracle front end + head pinned to reference code, trunk blocks "
                                             "restated from espnet2 — DESIGN.md §2)",
+                                "ms_per_step_small_batch": small,
                                 "roofline": embed_roofline(kern_e, B),
                                 "kernels_ms_per_step": {k: v["total_ms"] for k, v in kern_e.items()}}
             log(f"embed B=64: {ms:.3f} ms")
