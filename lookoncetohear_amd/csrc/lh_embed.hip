@@ -865,15 +865,18 @@ __global__ void __launch_bounds__(ER_NT, 1) k_emb_rec(const _Float16* __restrict
 //           columns (direction, unit, gate);  bih [2][256] in the same column order (b_ih + b_hh + W_ih beta)
 //   whh     fp32 [2][256][64], row 4 unit + gate
 // ---------------------------------------------------------------------------------------------------------------
-// Two workgroups per CU (52 KB of LDS, <= 128 registers): the recurrence only occupies one wave per SIMD and is latency, not
-// issue — a second sequence on the same CU costs little, and 2 x 256 resident workgroups take 2 B 65 <= 512 (B <= 3) in ONE round
-// (B = 2 is 260 workgroups: with one per CU a second round for FOUR of them doubled the pass).
+// Workgroups of FOUR waves (one per SIMD, every thread a recurrence thread), 52 KB of LDS and <= 128 registers: three workgroups per
+// CU.  The step is latency, not issue — further sequences on the same CU cost little — and 3 x 256 resident workgroups take
+// 2 B 65 <= 768 (B <= 5) in ONE round.  (First version: 512 threads, 64-step chunks, 200 registers = one per CU: B = 2's 260
+// workgroups needed a second round for FOUR of them; second: two per CU: B = 4's 520 a second round for eight.)
 constexpr int MV_TC = 32;                          // steps per chunk
 constexpr int MV_ROWS = MV_TC + EKS - 1;           // 35 position rows per chunk
 constexpr int MV_RP = 41;                          // odd row pitch of the staged rows (16-byte slots), like k_emb_gx
 constexpr int MV_HP = H + 8;                       // fp16 row pitch of the chunk's hidden states (144 B: 16-byte aligned rows)
 
-__global__ void __launch_bounds__(IS_NT, 2) k_emb_inter_mv(const _Float16* __restrict__ xs, const _Float16* __restrict__ wih_pk,
+constexpr int MV_NT = IS_NR;                       // 256 threads: thread 4 u + s = hidden unit u, k slice s (lh_quad.h)
+
+__global__ void __launch_bounds__(MV_NT, 3) k_emb_inter_mv(const _Float16* __restrict__ xs, const _Float16* __restrict__ wih_pk,
                                                         const float* __restrict__ bih, const float* __restrict__ whh,
                                                         _Float16* __restrict__ hs, int nseq, int P, int T, long rows_x) {
     __shared__ __attribute__((aligned(16))) _Float16 ahi[8 * MV_RP * 8];
@@ -889,10 +892,10 @@ __global__ void __launch_bounds__(IS_NT, 2) k_emb_inter_mv(const _Float16* __res
     const _Float16* xh = xs;
     const _Float16* xl = xs + rows_x * C;
 
-    const int unit = (tid & (IS_NR - 1)) >> 2, qs = tid & 3;             // recurrence role (threads < 256): unit, k slice
+    const int unit = tid >> 2, qs = tid & 3;                             // recurrence role: hidden unit, k slice
     f32x2 wr[4][8];
     quad_load_w(whh + (long)dir * IS_GP * H, unit, qs, wr);
-    const bool cell_lane = qs == 1 && tid < IS_NR;
+    const bool cell_lane = qs == 1;
     const float gscale = quad_gate_scale(qs);
     float c = 0.f;                                                         // QS_K2 x cell state; the embedder carries none
     if (tid < H) hprev[0][tid] = 0.f;
@@ -904,19 +907,19 @@ __global__ void __launch_bounds__(IS_NT, 2) k_emb_inter_mv(const _Float16* __res
         const int p0 = dir ? max(P - (ci + 1) * MV_TC, 0) : ci * MV_TC;
         const int n = dir ? (P - ci * MV_TC) - p0 : min(MV_TC, P - p0);
         // ---- stage position rows p0 .. p0 + n + 2 (16-byte copies of the pre-split images)
-        for (int e = tid; e < MV_ROWS * 8; e += IS_NT) {
+        for (int e = tid; e < MV_ROWS * 8; e += MV_NT) {
             const long off = pos_row<true>(seq, min(p0 + (e >> 3), L - 1), T) * C + (e & 7) * 8;
             const int idx = ((e & 7) * MV_RP + (e >> 3)) * 8;
             *reinterpret_cast<f16x8*>(&ahi[idx]) = *reinterpret_cast<const f16x8*>(&xh[off]);
             *reinterpret_cast<f16x8*>(&alo[idx]) = *reinterpret_cast<const f16x8*>(&xl[off]);
         }
         __syncthreads();
-        // ---- G_x[step][col] = b[col] + sum_{slot, c} xhat[step + slot][c] W'[col][slot*64 + c]: wave w owns column tiles 2w, 2w+1;
+        // ---- G_x[step][col] = b[col] + sum_{slot, c} xhat[step + slot][c] W'[col][slot*64 + c]: wave w owns column tiles 4w .. 4w+3;
         //      k-step outermost with the chunk's row tiles as accumulators: every weight fragment is fetched (L2) once per chunk and
         //      only one k-step of them is live (the 128-register budget of two workgroups per CU)
 #pragma unroll 1
-        for (int i = 0; i < 16 / IS_NW; ++i) {
-            const int nt = (16 / IS_NW) * wave + i;
+        for (int i = 0; i < 16 / (MV_NT / 64); ++i) {
+            const int nt = (16 / (MV_NT / 64)) * wave + i;
             const float bz = bih[dir * IS_GP + nt * 16 + l15];
             f32x4 am[MV_TC / 16], ac[MV_TC / 16];
 #pragma unroll
@@ -943,27 +946,22 @@ __global__ void __launch_bounds__(IS_NT, 2) k_emb_inter_mv(const _Float16* __res
         }
         __syncthreads();
         // ---- recurrence over the chunk's steps (lh_quad.h); h_t also goes into the chunk's fp16 rows
-        if (tid >= IS_NR) {
-            for (int j = 0; j < n; ++j) QS_SYNC();
-            hb ^= n & 1;
-        } else {
-            for (int j = 0; j < n; ++j) {
-                const int row = dir ? n - 1 - j : j;                         // natural step p0 + row
-                const float gx = gscale * gxs[row * IS_GP + tid];
-                const float hv = quad_step(wr, hprev[hb] + 16 * qs, gx, c, qs);
-                if (cell_lane) {
-                    hprev[hb ^ 1][unit] = hv;
-                    _Float16 th, tl;
-                    split_hl(hv, th, tl);
-                    hh[row * MV_HP + unit] = th;
-                    hl[row * MV_HP + unit] = tl;
-                }
-                hb ^= 1;
-                QS_SYNC();
+        for (int j = 0; j < n; ++j) {
+            const int row = dir ? n - 1 - j : j;                             // natural step p0 + row
+            const float gx = gscale * gxs[row * IS_GP + tid];
+            const float hv = quad_step(wr, hprev[hb] + 16 * qs, gx, c, qs);
+            if (cell_lane) {
+                hprev[hb ^ 1][unit] = hv;
+                _Float16 th, tl;
+                split_hl(hv, th, tl);
+                hh[row * MV_HP + unit] = th;
+                hl[row * MV_HP + unit] = tl;
             }
+            hb ^= 1;
+            QS_SYNC();
         }
         // ---- the chunk's hidden states: hi | lo images [row][128], this direction's 64 columns, 16-byte pieces
-        for (int e = tid; e < n * 16; e += IS_NT) {
+        for (int e = tid; e < n * 16; e += MV_NT) {
             const int row = e >> 4, piece = e & 15;
             _Float16* dst = hs + (piece < 8 ? 0 : hrows * 128) + ((long)seq * P + p0 + row) * 128 + dir * H + (piece & 7) * 8;
             *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(&(piece < 8 ? hh : hl)[row * MV_HP + (piece & 7) * 8]);
@@ -2023,7 +2021,7 @@ extern "C" int lh_emb_axis_mv(const float* x, const void* wih_pk, const float* b
     const int ctiles = nseq * ((T + CtShape<true>::RT - 1) / CtShape<true>::RT);
     if (!have_xsplit)
         hipLaunchKernelGGL(k_emb_lnsplit, dim3((unsigned)(lnb < 4096 ? lnb : 4096)), dim3(256), 0, st, x, (_Float16*)xsplit, rows);
-    hipLaunchKernelGGL(k_emb_inter_mv, dim3(2 * nseq), dim3(IS_NT), 0, st, (const _Float16*)xsplit, (const _Float16*)wih_pk, bih,
+    hipLaunchKernelGGL(k_emb_inter_mv, dim3(2 * nseq), dim3(MV_NT), 0, st, (const _Float16*)xsplit, (const _Float16*)wih_pk, bih,
                        whh, (_Float16*)hsplit, nseq, P, T, rows);
     hipLaunchKernelGGL((k_emb_convt2<true>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
                        (const _Float16*)wct_pk, bct, x, out, emit_split ? (_Float16*)xsplit : nullptr, rows, nseq, P, T);
