@@ -874,9 +874,10 @@ constexpr int MV_ROWS = MV_TC + EKS - 1;           // 35 position rows per chunk
 constexpr int MV_RP = 41;                          // odd row pitch of the staged rows (16-byte slots), like k_emb_gx
 constexpr int MV_HP = H + 8;                       // fp16 row pitch of the chunk's hidden states (144 B: 16-byte aligned rows)
 
-constexpr int MV_NT = IS_NR;                       // 256 threads: thread 4 u + s = hidden unit u, k slice s (lh_quad.h)
-
-__global__ void __launch_bounds__(MV_NT, 3) k_emb_inter_mv(const _Float16* __restrict__ xs, const _Float16* __restrict__ wih_pk,
+// MV_NT = 256 (three per CU) or 512 (two per CU; threads 256.. only work in the staging / GEMM phases and otherwise keep the step
+// barrier company: 4 % faster while one workgroup per CU is all there is — a single enrollment)
+template <int MV_NT>
+__global__ void __launch_bounds__(MV_NT, MV_NT == IS_NR ? 3 : 2) k_emb_inter_mv(const _Float16* __restrict__ xs, const _Float16* __restrict__ wih_pk,
                                                         const float* __restrict__ bih, const float* __restrict__ whh,
                                                         _Float16* __restrict__ hs, int nseq, int P, int T, long rows_x) {
     __shared__ __attribute__((aligned(16))) _Float16 ahi[8 * MV_RP * 8];
@@ -892,10 +893,10 @@ __global__ void __launch_bounds__(MV_NT, 3) k_emb_inter_mv(const _Float16* __res
     const _Float16* xh = xs;
     const _Float16* xl = xs + rows_x * C;
 
-    const int unit = tid >> 2, qs = tid & 3;                             // recurrence role: hidden unit, k slice
+    const int unit = (tid & (IS_NR - 1)) >> 2, qs = tid & 3;             // recurrence role (threads < 256): hidden unit, k slice
     f32x2 wr[4][8];
     quad_load_w(whh + (long)dir * IS_GP * H, unit, qs, wr);
-    const bool cell_lane = qs == 1;
+    const bool cell_lane = qs == 1 && tid < IS_NR;
     const float gscale = quad_gate_scale(qs);
     float c = 0.f;                                                         // QS_K2 x cell state; the embedder carries none
     if (tid < H) hprev[0][tid] = 0.f;
@@ -946,6 +947,10 @@ __global__ void __launch_bounds__(MV_NT, 3) k_emb_inter_mv(const _Float16* __res
         }
         __syncthreads();
         // ---- recurrence over the chunk's steps (lh_quad.h); h_t also goes into the chunk's fp16 rows
+        if (MV_NT > IS_NR && tid >= IS_NR) {
+            for (int j = 0; j < n; ++j) QS_SYNC();
+            hb ^= n & 1;
+        } else
         for (int j = 0; j < n; ++j) {
             const int row = dir ? n - 1 - j : j;                             // natural step p0 + row
             const float gx = gscale * gxs[row * IS_GP + tid];
@@ -2021,8 +2026,12 @@ extern "C" int lh_emb_axis_mv(const float* x, const void* wih_pk, const float* b
     const int ctiles = nseq * ((T + CtShape<true>::RT - 1) / CtShape<true>::RT);
     if (!have_xsplit)
         hipLaunchKernelGGL(k_emb_lnsplit, dim3((unsigned)(lnb < 4096 ? lnb : 4096)), dim3(256), 0, st, x, (_Float16*)xsplit, rows);
-    hipLaunchKernelGGL(k_emb_inter_mv, dim3(2 * nseq), dim3(MV_NT), 0, st, (const _Float16*)xsplit, (const _Float16*)wih_pk, bih,
-                       whh, (_Float16*)hsplit, nseq, P, T, rows);
+    if (2 * nseq <= 256)          // one workgroup per CU at most: the eight-wave form (its extra waves halve the input GEMM's time)
+        hipLaunchKernelGGL(k_emb_inter_mv<IS_NT>, dim3(2 * nseq), dim3(IS_NT), 0, st, (const _Float16*)xsplit, (const _Float16*)wih_pk,
+                           bih, whh, (_Float16*)hsplit, nseq, P, T, rows);
+    else
+        hipLaunchKernelGGL(k_emb_inter_mv<IS_NR>, dim3(2 * nseq), dim3(IS_NR), 0, st, (const _Float16*)xsplit, (const _Float16*)wih_pk,
+                           bih, whh, (_Float16*)hsplit, nseq, P, T, rows);
     hipLaunchKernelGGL((k_emb_convt2<true>), dim3(ctiles < 512 ? ctiles : 512), dim3(256), 0, st, (const _Float16*)hsplit,
                        (const _Float16*)wct_pk, bct, x, out, emit_split ? (_Float16*)xsplit : nullptr, rows, nseq, P, T);
     return check_launch();

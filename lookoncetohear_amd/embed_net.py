@@ -84,11 +84,11 @@ class EmbedTFGridNet(_cabi.HipHost, nn.Module):
         # library does not contain it and the call fails loudly)
         self.fused_axis = os.environ.get("LOOKONCE_EMB_FUSED", "1") != "0"
         self.n_streams = int(os.environ.get("LOOKONCE_EMB_STREAMS", "2"))
-        # inter-axis recurrence: one workgroup per (sequence, direction) (k_emb_inter_mv: ~0.4 us per step, two workgroups per CU)
-        # while those fit this many workgroups — B <= 5: one 5 s enrollment 5.66 -> 3.07 ms, two 6.18 -> 4.10, three 6.84 -> 4.87,
-        # four 7.45 -> 6.93, five 8.54 -> 8.04; six and seven measured equal (profiles/r06i_embed_small_batch.txt) — 16-sequence
+        # inter-axis recurrence: one workgroup per (sequence, direction) (k_emb_inter_mv: ~0.4 us per step, up to three workgroups per
+        # CU) while those fit this many workgroups — B <= 7: one 5 s enrollment 5.66 -> 3.07 ms, two 6.18 -> 4.13, three 6.84 -> 4.80,
+        # four 7.45 -> 5.91, five 8.54 -> 6.96, six 8.90 -> 8.73, seven 9.81 -> 9.67 (profiles/r06i_embed_small_batch.txt) — 16-sequence
         # tiles (k_emb_rec: ~1.4 us per step) above.  LOOKONCE_EMB_MV_MAX_WGS overrides.
-        self.inter_mv_max_wgs = int(os.environ.get("LOOKONCE_EMB_MV_MAX_WGS", "704"))
+        self.inter_mv_max_wgs = int(os.environ.get("LOOKONCE_EMB_MV_MAX_WGS", "1024"))
         self._side = None
         self._debug_taps: Optional[dict] = None
         self._prof: Optional[list] = None  # bench.py: (C-ABI call, start event, end event) per launch
