@@ -148,7 +148,7 @@ int lh_ln_lstm_inter(const float* x, const float* ln_w, const float* ln_b, const
 int lh_intra_stream(const float* x, const void* wih_pk, const float* b_sum, const float* whh, float* h_out,
                     int n_frames, lh_stream_t stream);
 
-/* A.3.2 + Linear fused for few sequences (batch <= 5): same result as lh_inter_block, one workgroup per sequence
+/* A.3.2 + Linear fused for few sequences (the host uses it while they fit one round of CUs: batch <= 2): same result as lh_inter_block, one workgroup per sequence
  * (b, f), 64-step chunks: input half and output projection as MFMA GEMMs around a mat-vec recurrence.
  *   x, out [B][T][97][64] (must not alias); h0, c0, hN, cN [B*97][64]
  *   wih_pk [16 ntiles][2 ksteps][64 lanes][16], b_sum [256], whh [512][32]: the lh_intra_stream layouts for the inter
@@ -290,7 +290,7 @@ int lh_ln_lstm_intra_win(const float* x, const float* ln_w, const float* ln_b, c
                          int B, int T, int t0, int Tc, lh_stream_t stream);
 int lh_linear_res_win(const float* h, const void* w_pk, const float* bias, const float* res, float* out, int B, int T, int t0,
                       int Tc, int K, lh_stream_t stream);
-/* the batch <= 5 form of the inter stage (lh_inter_matvec) on a window; `carry` as above.  Windows that start on multiples of
+/* the few-sequences form of the inter stage (lh_inter_matvec) on a window; `carry` as above.  Windows that start on multiples of
  * its 64-step chunk reproduce the whole-clip launch bit for bit. */
 int lh_inter_matvec_win(const float* x, const void* wih_pk, const float* b_sum, const float* whh, const void* wlin_pk,
                         const float* blin, const float* h0, const float* c0, float* hN, float* cN, float* out, int B, int T,

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(IS_NT) k_intra_stream(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Inter-frame LSTM for few sequences (batch 1-5 offline): LayerNorm -> causal LSTM over time with carried (h, c) ->
+// Inter-frame LSTM for few sequences (batch 1-2 offline since round 6; the kernel serves any number): LayerNorm -> causal LSTM over time with carried (h, c) ->
 // Linear(64->64) -> + residual  (tfgridnet_causal.py:521-538), one workgroup per sequence (b, f).
 // The tiled kernel (k_ln_lstm_lin) needs 16 sequences per workgroup: at batch 1 that is 7 workgroups walking 625
 // steps at ~1.1 us each (0.7 ms per block, 2.1 of the 3.0 ms forward).  Here every sequence gets its own CU and the

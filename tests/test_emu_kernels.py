@@ -249,7 +249,7 @@ def test_tiled_intra_kernel_forced_small(emu_net, oracle_cfg_sd):
 
 
 def test_inter_matvec_two_chunks(emu_net, oracle_cfg_sd):
-    """Per-sequence inter LSTM (lh_inter_matvec, batch <= 5 and T >= 32): T = 70 = one full 64-step chunk + a ragged one,
+    """Per-sequence inter LSTM (lh_inter_matvec, batch <= 2 and T >= 32): T = 70 = one full 64-step chunk + a ragged one,
     carried (h, c) in and out, against the oracle; the tiled kernel (lh_inter_block) on the same input must agree."""
     cfg, sd = oracle_cfg_sd
     B, T = 1, 70
