@@ -546,3 +546,28 @@ def test_time_chunks_are_bit_identical_to_the_whole_clip(nets, oracle_cfg_sd):
                     assert torch.equal(net(mm, em), ym), (Bm, rep)
     finally:
         net.time_chunks, net.time_chunks_small = saved_chunks
+
+
+def test_windowed_forward_is_capturable_in_a_hip_graph(nets):
+    """The forward with time windows (side streams forked from and joined to the caller's stream, two cross-stream events per block
+    and window) captured by the CALLER into a hipGraph and replayed: bit-identical to the eager forward (B = 1: two windows and the
+    per-sequence inter kernel; B = 8: three windows and the tiled one)."""
+    net = nets["f16x3"]
+    d = synth.batch(list(range(8)), 80000)
+    with torch.no_grad():
+        for B in (1, 8):
+            mix, emb = d["mixture"][:B].to(DEV).contiguous(), d["embedding_gt"][:B].to(DEV).contiguous()
+            assert net._n_time_chunks(B, 625, 1) > 1
+            y0 = net(mix, emb).clone()                     # (also the warm-up: workspace, per-block K / V pairs, window streams)
+            side = torch.cuda.Stream(device=DEV)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                net(mix, emb)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                y = net(mix, emb)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y, y0), B
