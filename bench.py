@@ -836,6 +836,21 @@ def secondary_measurements(net, dev, mix8, emb8):
                               "workload": "enroll -> embedding -> separate -> metric sums, 32 x (5 s enrollment + 5 s mixture), one "
                                           "stream (reference src/ts_hear_test.py:132-146)"}
             log(f"e2e B=32: {ms:.3f} ms (embedder {ms_e:.3f})")
+            # the same loop at the reference's own eval batch of 4 (src/ts_hear_test.py:121): both halves latency-bound there — the
+            # embedder's inter axis on one workgroup per (sequence, direction), the separator in three time windows (round 6)
+            mix4, enr4, tgt4, egt4 = mix[:4].contiguous(), enr[:4].contiguous(), tgt[:4].contiguous(), egt[:4].contiguous()
+
+            def chain4():
+                e = enet(enr4).unsqueeze(1)
+                y = net(mix4, e)
+                return metric_sums_device(y, mix4, tgt4, e[:, 0], egt4[:, 0])[0]
+
+            ms4 = _time_forward(chain4, 10, 3)
+            ms4_e = _time_forward(lambda: enet(enr4), 10, 3)
+            out["e2e_b4"] = {"ms_per_step": ms4, "clips_per_s": 4 / ms4 * 1e3, "embedder_ms": ms4_e, "separator_and_metrics_ms": ms4 - ms4_e,
+                             "workload": "enroll -> embedding -> separate -> metric sums at the reference's eval batch: 4 x (5 s enrollment + "
+                                         "5 s mixture), one caller stream"}
+            log(f"e2e B=4: {ms4:.3f} ms (embedder {ms4_e:.3f})")
             del enet, mix, enr, tgt, egt
         except Exception as e:
             out["e2e_b32"] = {"error": repr(e)[:200]}
